@@ -1,0 +1,125 @@
+/*
+ * pogs_rast.h -- C ABI of the MI355X (gfx950) Gaussian-splat rasterizer library, libpogs_rast.so.
+ *
+ * The library is the device half of the drop-in for `gsplat.rendering.rasterization()`, the call the
+ * reference makes at pogs/pogs.py:352-371, :419-437, :493-510, :930-948 and (through get_outputs) from
+ * pogs/tracking/rigid_group_optimizer.py:299,314,545.  gsplat itself is a third-party dependency that is
+ * not part of the reference tree (pinned gsplat==1.4.0 at
+ * src/pogs/dependencies/nerfstudio/pyproject.toml:67); each entry point below names the gsplat 1.4.0
+ * routine (`gsplat/cuda/_wrapper.py`) whose CUDA extension call it stands in for.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its comment says "host";
+ *   - every array is dense, row-major, float32 unless typed otherwise;
+ *   - the caller owns every buffer (inputs, outputs, scratch); the library allocates nothing persistent;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises the device
+ *     except where documented;
+ *   - return value: 0 on success, a negative PR_E* code otherwise (never throws, never aborts);
+ *     pr_error_string() maps a code to text;
+ *   - N = Gaussians, C = cameras, flat index = c*N + n, D = composited channels.
+ */
+#ifndef POGS_RAST_H
+#define POGS_RAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PR_OK 0
+#define PR_EINVAL (-1)      /* bad argument (null pointer, negative size, unsupported value) */
+#define PR_EUNSUPPORTED (-2)/* valid request the library has no kernel for (e.g. channel count too large) */
+#define PR_ESCRATCH (-3)    /* scratch buffer too small */
+#define PR_EHIP (-4)        /* a HIP runtime call or launch failed; hipGetLastError text via pr_last_hip_error */
+
+/* Library/ABI version, (major<<16)|minor. */
+int pr_version(void);
+const char *pr_error_string(int code);
+/* Text of the last HIP error seen by the calling thread (empty string if none). Host pointer. */
+const char *pr_last_hip_error(void);
+/* Largest channel count pr_raster_fwd / pr_raster_bwd accept in one call. */
+int pr_max_channels(void);
+
+/* ---- projection: stands in for gsplat `fully_fused_projection` forward (non-packed) --------------------
+ * means[N,3] quats[N,4] (wxyz, unnormalised) scales[N,3] viewmats[C,4,4] (world->camera) Ks[C,3,3].
+ * Out: radii[C,N] int32 (0 = culled), means2d[C,N,2], depths[C,N], conics[C,N,3],
+ *      compensations[C,N] (may be NULL: not computed).  Culled entries are written as zeros. */
+int pr_project_fwd(int C, int N, const float *means, const float *quats, const float *scales,
+                   const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                   float near_plane, float far_plane, float radius_clip, int32_t *radii, float *means2d,
+                   float *depths, float *conics, float *compensations, void *stream);
+
+/* ---- projection backward: stands in for gsplat `fully_fused_projection` backward ------------------------
+ * v_means2d[C,N,*] with row stride ld_means2d floats, v_conics[C,N,*] with row stride ld_conics,
+ * v_depths[C,N] (may be NULL), v_compensations[C,N] (may be NULL).
+ * Out (overwritten): v_means[N,3], v_quats[N,4], v_scales[N,3] -- summed over cameras.
+ * v_viewmats[C,4,4] may be NULL; otherwise it must be zero-filled by the caller and rows 0..2 are
+ * accumulated into with float atomics. */
+int pr_project_bwd(int C, int N, const float *means, const float *quats, const float *scales,
+                   const float *viewmats, const float *Ks, int width, int height, float eps2d,
+                   const int32_t *radii, const float *v_means2d, int ld_means2d, const float *v_depths,
+                   const float *v_conics, int ld_conics, const float *v_compensations, float *v_means,
+                   float *v_quats, float *v_scales, float *v_viewmats, void *stream);
+
+/* ---- spherical harmonics: stands in for gsplat `spherical_harmonics` forward/backward -------------------
+ * View directions are means[n] - campos[c] (campos[C,3] = camera centres in world coordinates).
+ * coeffs[N,K,3]; degree in 0..3 with (degree+1)^2 <= K.  Entries with radii[c,n] <= 0 are masked.
+ * post != 0 fuses the caller's `clamp_min(x + 0.5, 0)` (pogs colour convention) into the kernel.
+ * colors out: [C,N,3] with row stride ld_colors floats. */
+int pr_sh_fwd(int C, int N, int K, int degree, const float *means, const float *campos,
+              const float *coeffs, const int32_t *radii, int post, float *colors, int ld_colors,
+              void *stream);
+/* Out (overwritten): v_coeffs[N,K,3] (summed over cameras; zero for inactive bands),
+ * v_means[N,3] (gradient through the view direction, summed over cameras; may be NULL),
+ * v_campos[C,3] (may be NULL; otherwise zero-filled by the caller, accumulated with atomics). */
+int pr_sh_bwd(int C, int N, int K, int degree, const float *means, const float *campos,
+              const float *coeffs, const int32_t *radii, int post, const float *v_colors, int ld_colors,
+              float *v_coeffs, float *v_means, float *v_campos, void *stream);
+
+/* ---- tile binning: stands in for gsplat `isect_tiles` + `isect_offset_encode` --------------------------
+ * Phase 1: tiles_per_gauss[C,N] int32 and its inclusive prefix sum cum_tiles[C*N] int64.
+ * The caller reads cum_tiles[C*N-1] back to the host to learn n_isects (the only D2H of the path),
+ * then calls phase 2 with buffers of that size. */
+size_t pr_isect_count_scratch_bytes(int C, int N);
+int pr_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size, int tile_w,
+                   int tile_h, int32_t *tiles_per_gauss, int64_t *cum_tiles, void *scratch,
+                   size_t scratch_bytes, void *stream);
+/* Phase 2: emit key = cam<<(32+tile_bits) | tile<<32 | float_bits(depth) and value = flat index, then
+ * stable ascending sort by key.  Out: isect_ids[n_isects] int64, flatten_ids[n_isects] int32. */
+size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects);
+int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                       const int64_t *cum_tiles, int tile_size, int tile_w, int tile_h, int64_t n_isects,
+                       int64_t *isect_ids, int32_t *flatten_ids, void *scratch, size_t scratch_bytes,
+                       void *stream);
+/* isect_offsets[C,tile_h,tile_w] int32: index of the first intersection of every (camera, tile). */
+int pr_isect_offsets(int64_t n_isects, const int64_t *isect_ids, int C, int tile_w, int tile_h,
+                     int32_t *isect_offsets, void *stream);
+
+/* ---- compositing: stands in for gsplat `rasterize_to_pixels` forward/backward --------------------------
+ * means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] backgrounds[C,D] (may be NULL).
+ * Out: render_colors[C,H,W,D], render_alphas[C,H,W], last_ids[C,H,W] int32 (one past the index of the
+ * last intersection that contributed to the pixel; the tile's first index when none did). */
+int pr_raster_fwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
+                  const float *opacities, const float *backgrounds, int width, int height, int tile_size,
+                  int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                  int64_t n_isects, float *render_colors, float *render_alphas, int32_t *last_ids,
+                  void *stream);
+/* v_render_colors[C,H,W,D], v_render_alphas[C,H,W].
+ * Out, all zero-filled by the caller and accumulated into with float atomics:
+ *   v_geom[C*N,8] = (v_means2d.x, v_means2d.y, v_conic.a, v_conic.b, v_conic.c, v_opacity,
+ *                    |v_means2d|.x, |v_means2d|.y)  -- the last two only when absgrad != 0;
+ *   v_colors[C*N,D] (may be NULL: colour gradients not needed).
+ * geom_grad == 0 skips every geometry gradient (v_geom may then be NULL). */
+int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
+                  const float *opacities, const float *backgrounds, int width, int height, int tile_size,
+                  int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                  int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
+                  const float *v_render_colors, const float *v_render_alphas, int absgrad, int geom_grad,
+                  float *v_geom, float *v_colors, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POGS_RAST_H */

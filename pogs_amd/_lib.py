@@ -1,0 +1,70 @@
+"""ctypes binding of ``libpogs_rast.so`` (the C ABI declared in ``include/pogs_rast.h``).
+
+The library is built in-tree by ``pogs_amd/csrc/Makefile`` (``__graft_entry__.build()`` drives it).
+There is NO fallback: if the shared object is missing or a symbol is absent, importing the
+rasterizer fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpogs_rast.so")
+
+_P = c_void_p
+
+# name -> (restype, argtypes); mirrors include/pogs_rast.h one to one.
+SIGNATURES = {
+    "pr_version": (c_int, []),
+    "pr_error_string": (c_char_p, [c_int]),
+    "pr_last_hip_error": (c_char_p, []),
+    "pr_max_channels": (c_int, []),
+    "pr_project_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float,
+                               _P, _P, _P, _P, _P, _P]),
+    "pr_project_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P, c_int, _P, _P, c_int,
+                               _P, _P, _P, _P, _P, _P]),
+    "pr_sh_fwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P]),
+    "pr_sh_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, _P]),
+    "pr_isect_count_scratch_bytes": (c_size_t, [c_int, c_int]),
+    "pr_isect_count": (c_int, [c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "pr_isect_sort_scratch_bytes": (c_size_t, [c_int, c_int, c_int64]),
+    "pr_isect_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t,
+                                   _P]),
+    "pr_isect_offsets": (c_int, [c_int64, _P, c_int, c_int, c_int, _P, _P]),
+    "pr_raster_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P,
+                              c_int64, _P, _P, _P, _P]),
+    "pr_raster_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P,
+                              c_int64, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library once and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C pogs_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "pogs_amd has no CPU or PyTorch fallback for the rasterizer.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load()
+        msg = lib.pr_error_string(rc).decode()
+        if rc == -4:
+            msg += ": " + lib.pr_last_hip_error().decode()
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")

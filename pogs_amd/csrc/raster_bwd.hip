@@ -1,0 +1,297 @@
+// Backward compositing kernel for gfx950: back-to-front replay of each tile's list, per-Gaussian
+// totals reduced over the wavefront's pixels before ONE contiguous float-atomic per Gaussian.
+//
+// Algebra (per pixel, walking the list backwards; T = transmittance in front of the Gaussian):
+//   ra = 1/(1-alpha);  T *= ra;  fac = alpha*T
+//   S  = <colour_g, v_out_pixel>                      (one dot product per pair)
+//   v_alpha = S*T - (B - W)*ra,   B = sum over Gaussians BEHIND g of fac*S,
+//             W = T_final*(v_alpha_out - <background, v_out_pixel>)
+//   v_colour_g += fac * v_out_pixel
+// Keeping the scalar B instead of a per-channel "colour behind" buffer halves the per-pair channel
+// work and removes D registers per pixel.
+#include "raster_common.h"
+
+namespace pr {
+
+template <int TS, int PPL, int CD, bool GEOM>
+__global__ void __launch_bounds__(256) raster_bwd_kernel(
+    int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
+    int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
+    const int32_t *__restrict__ flatten_ids, int n_isects, const float *__restrict__ render_alphas,
+    const int32_t *__restrict__ last_ids, const float *__restrict__ v_render_colors,
+    const float *__restrict__ v_render_alphas, int absgrad, float *__restrict__ v_geom,
+    float *__restrict__ v_colors) {
+  using Rg = Region<TS, PPL>;
+  constexpr int ROW = color_row(CD);
+  constexpr int CDP = round4(CD);
+  __shared__ WaveLds<CD> lds[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int region = (int)bid * 4 + wave;
+  if (region >= n_regions) return;
+  WaveLds<CD> &L = lds[wave];
+
+  const int tile_flat = region / Rg::WPT, sub = region % Rg::WPT;
+  const int n_tiles = tile_w * tile_h;
+  const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
+  const int ty = tile / tile_w, tx = tile % tile_w;
+  const int x0 = tx * TS + (lane % Rg::LX) * Rg::BW;
+  const int y0 = ty * TS + sub * Rg::RH + (lane / Rg::LX) * Rg::BH;
+  const int range_lo = isect_offsets[tile_flat];
+  const int nch = min(CD, D - ch_off);
+
+  float T[PPL], Bsum[PPL], W[PPL], vout[PPL][CD];
+  int last[PPL];
+  const float px0 = (float)x0 + 0.5f, py0 = (float)y0 + 0.5f;
+  int max_last = range_lo;
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    const int x = x0 + (j % Rg::BW), y = y0 + (j / Rg::BW);
+    const bool inside = x < width && y < height;
+    const int64_t pix = ((int64_t)cam * height + y) * width + x;
+    T[j] = 1.f;
+    Bsum[j] = 0.f;
+    W[j] = 0.f;
+    last[j] = range_lo;
+#pragma unroll
+    for (int k = 0; k < CD; ++k) vout[j][k] = 0.f;
+    if (inside) {
+      T[j] = 1.f - render_alphas[pix];
+      last[j] = last_ids[pix];
+      const float *src = v_render_colors + pix * D + ch_off;
+      if (((D | ch_off) & 3) == 0) {
+#pragma unroll
+        for (int k = 0; k + 3 < CD; k += 4)
+          if (k < nch) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + k);
+            vout[j][k] = v.x; vout[j][k + 1] = v.y; vout[j][k + 2] = v.z; vout[j][k + 3] = v.w;
+          }
+      } else {
+#pragma unroll
+        for (int k = 0; k < CD; ++k)
+          if (k < nch) vout[j][k] = src[k];
+      }
+      if (GEOM) {
+        float w = v_render_alphas[pix];
+        if (backgrounds) {
+          const float *bg = backgrounds + (int64_t)cam * D + ch_off;
+#pragma unroll
+          for (int k = 0; k < CD; ++k)
+            if (k < nch) w -= bg[k] * vout[j][k];
+        }
+        W[j] = T[j] * w;
+      }
+    }
+    max_last = max(max_last, last[j]);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) max_last = max(max_last, __shfl_xor(max_last, m));
+
+  for (int bend = max_last; bend > range_lo; bend -= WAVE) {
+    const int first = max(range_lo, bend - WAVE);
+    const int count = bend - first;
+    stage_batch<CD>(L, lane, first, count, flatten_ids, means2d, conics, opacities, colors, D, ch_off);
+    for (int t = count - 1; t >= 0; --t) {
+      const int idx = first + t;
+      const float4 g = L.g4[t];
+      const float2 h = L.g2[t];
+      float dx[Rg::BW], dy[Rg::BH], adx2[Rg::BW], cdy2[Rg::BH], bdx[Rg::BW];
+#pragma unroll
+      for (int i = 0; i < Rg::BW; ++i) {
+        dx[i] = g.x - (px0 + (float)i);
+        adx2[i] = g.w * dx[i] * dx[i];
+        bdx[i] = h.x * dx[i];
+      }
+#pragma unroll
+      for (int i = 0; i < Rg::BH; ++i) {
+        dy[i] = g.y - (py0 + (float)i);
+        cdy2[i] = h.y * dy[i] * dy[i];
+      }
+      float e[PPL], alpha[PPL];
+      bool active[PPL], any = false;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const int jx = j % Rg::BW, jy = j / Rg::BW;
+        const float power = adx2[jx] + cdy2[jy] + bdx[jx] * dy[jy];
+        e[j] = __builtin_amdgcn_exp2f(power);
+        alpha[j] = fminf(ALPHA_MAX, g.z * e[j]);
+        active[j] = (power <= 0.f) && (alpha[j] >= ALPHA_MIN) && (idx < last[j]);
+        any = any || active[j];
+      }
+      if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
+
+      float fac[PPL], ra[PPL];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        ra[j] = __builtin_amdgcn_rcpf(1.f - alpha[j]);
+        T[j] = active[j] ? T[j] * ra[j] : T[j];
+        fac[j] = active[j] ? alpha[j] * T[j] : 0.f;
+      }
+      float S[PPL], vc[CD];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) S[j] = 0.f;
+      const float4 *crow = reinterpret_cast<const float4 *>(L.col + t * ROW);
+#pragma unroll
+      for (int q = 0; q < CDP / 4; ++q) {
+        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (GEOM) c4 = crow[q];
+        const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int ei = 0; ei < 4; ++ei) {
+          const int k = 4 * q + ei;
+          if (k < CD) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+              if (GEOM) S[j] = fmaf(cv[ei], vout[j][k], S[j]);
+              a = fmaf(fac[j], vout[j][k], a);
+            }
+            vc[k] = a;
+          }
+        }
+      }
+      float geo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // x y a b c o |x| |y|
+      if (GEOM) {
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+          const int jx = j % Rg::BW, jy = j / Rg::BW;
+          const float v_alpha = S[j] * T[j] - (Bsum[j] - W[j]) * ra[j];
+          Bsum[j] = fmaf(fac[j], S[j], Bsum[j]);
+          const float ar = g.z * e[j];
+          const bool gr = active[j] && (ar <= ALPHA_MAX);
+          const float vs = gr ? -ar * v_alpha : 0.f;  // d loss / d sigma
+          geo[5] += gr ? e[j] * v_alpha : 0.f;
+          const float t1 = vs * dx[jx], t2 = vs * dy[jy];
+          geo[2] = fmaf(t1, dx[jx], geo[2]);
+          geo[3] = fmaf(t1, dy[jy], geo[3]);
+          geo[4] = fmaf(t2, dy[jy], geo[4]);
+          const float gx = 2.f * g.w * dx[jx] + h.x * dy[jy];  // = -log2e * (a dx + b dy)
+          const float gy = h.x * dx[jx] + 2.f * h.y * dy[jy];
+          const float vx = vs * gx, vy = vs * gy;
+          geo[0] += vx;
+          geo[1] += vy;
+          geo[6] += fabsf(vx);
+          geo[7] += fabsf(vy);
+        }
+      }
+      // wave totals -> lane 63 -> LDS -> one lane per value -> atomics
+#pragma unroll
+      for (int k = 0; k < CD; ++k) vc[k] = wave_sum_to_lane63(vc[k]);
+      if (GEOM) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) geo[k] = wave_sum_to_lane63(geo[k]);
+      }
+      if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k + 3 < CDP; k += 4) {
+          float4 v;
+          v.x = vc[k];
+          v.y = (k + 1 < CD) ? vc[k + 1] : 0.f;
+          v.z = (k + 2 < CD) ? vc[k + 2] : 0.f;
+          v.w = (k + 3 < CD) ? vc[k + 3] : 0.f;
+          *reinterpret_cast<float4 *>(L.red + k) = v;
+        }
+        if (GEOM) {
+          *reinterpret_cast<float4 *>(L.red + CDP) =
+              make_float4(-LN2 * geo[0], -LN2 * geo[1], 0.5f * geo[2], geo[3]);
+          *reinterpret_cast<float4 *>(L.red + CDP + 4) = make_float4(0.5f * geo[4], geo[5], LN2 * geo[6], LN2 * geo[7]);
+        }
+      }
+      const int gid = L.ids[t];
+      if (v_colors) {
+#pragma unroll
+        for (int k0 = 0; k0 < CD; k0 += WAVE) {
+          const int k = k0 + lane;
+          if (k < nch) atomicAdd(v_colors + (int64_t)gid * D + ch_off + k, L.red[k]);
+        }
+      }
+      if (GEOM) {
+        const int ng = absgrad ? 8 : 6;
+        if (lane < ng) atomicAdd(v_geom + (int64_t)gid * 8 + lane, L.red[CDP + lane]);
+      }
+    }
+  }
+}
+
+template <int TS, int PPL, int CD, bool GEOM>
+static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const float *colors,
+                      const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
+                      const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                      const float *render_alphas, const int32_t *last_ids, const float *v_render_colors,
+                      const float *v_render_alphas, int absgrad, float *v_geom, float *v_colors, hipStream_t stream) {
+  const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
+  const unsigned grid = (unsigned)((n_regions + 3) / 4);
+  hipLaunchKernelGGL((raster_bwd_kernel<TS, PPL, CD, GEOM>), dim3(grid), dim3(256), 0, stream, (int)n_regions, N, D,
+                     ch_off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h,
+                     isect_offsets, flatten_ids, (int)n_isects, render_alphas, last_ids, v_render_colors,
+                     v_render_alphas, absgrad, v_geom, v_colors);
+  return check_launch("raster_bwd_kernel");
+}
+
+static const int kChunks[] = {4, 8, 16, 24, 32, 36, 48, 64, 100, 128};
+static int pick_chunk(int want) {
+  for (int c : kChunks)
+    if (c >= want) return c;
+  return -1;
+}
+
+}  // namespace pr
+
+using namespace pr;
+
+extern "C" int pr_max_channels(void) { return 128; }
+
+#define BWD_ARGS                                                                                                     \
+  C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,       \
+      flatten_ids, n_isects, render_alphas, last_ids, v_render_colors, v_render_alphas, absgrad, v_geom, v_colors,   \
+      (hipStream_t)stream
+#define BWD_CASE(TS, PPL, CDV)                                      \
+  case CDV:                                                         \
+    rc = geom_grad ? launch_bwd<TS, PPL, CDV, true>(BWD_ARGS)       \
+                   : launch_bwd<TS, PPL, CDV, false>(BWD_ARGS);     \
+    break;
+
+extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
+                             const float *opacities, const float *backgrounds, int width, int height, int tile_size,
+                             int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                             int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
+                             const float *v_render_colors, const float *v_render_alphas, int absgrad, int geom_grad,
+                             float *v_geom, float *v_colors, void *stream) {
+  if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)
+    return PR_EINVAL;
+  if (tile_size != 16 && tile_size != 8) return PR_EUNSUPPORTED;
+  if (D > pr_max_channels() || n_isects > 2147483647ll) return PR_EUNSUPPORTED;
+  if ((int64_t)tile_w * tile_size < width || (int64_t)tile_h * tile_size < height) return PR_EINVAL;
+  if (C == 0 || n_isects == 0) return PR_OK;
+  if (!means2d || !conics || !colors || !opacities || !isect_offsets || !flatten_ids || !render_alphas || !last_ids ||
+      !v_render_colors || !v_render_alphas)
+    return PR_EINVAL;
+  if (geom_grad && !v_geom) return PR_EINVAL;
+  if (!geom_grad && !v_colors) return PR_OK;
+  if ((int64_t)C * tile_w * tile_h * 4 > 2147483647ll) return PR_EUNSUPPORTED;
+  // Geometry gradients need the dot product over ALL channels in one pass; colour-only gradients can
+  // be chunked freely, and narrow chunks keep 4 pixels per lane.
+  int per = D;
+  if (!geom_grad && D > 36) {
+    const int n_chunks = (D + 35) / 36;
+    per = ((D + n_chunks - 1) / n_chunks + 3) & ~3;
+  }
+  for (int off = 0; off < D; off += per) {
+    const int cd = pick_chunk(min(per, D - off));
+    int rc = PR_EUNSUPPORTED;
+    if (tile_size == 16) {
+      switch (cd) {
+        BWD_CASE(16, 4, 4) BWD_CASE(16, 4, 8) BWD_CASE(16, 4, 16) BWD_CASE(16, 4, 24) BWD_CASE(16, 4, 32)
+        BWD_CASE(16, 4, 36) BWD_CASE(16, 2, 48) BWD_CASE(16, 2, 64) BWD_CASE(16, 1, 100) BWD_CASE(16, 1, 128)
+      }
+    } else {
+      switch (cd) {
+        BWD_CASE(8, 1, 4) BWD_CASE(8, 1, 8) BWD_CASE(8, 1, 16) BWD_CASE(8, 1, 24) BWD_CASE(8, 1, 32)
+        BWD_CASE(8, 1, 36) BWD_CASE(8, 1, 48) BWD_CASE(8, 1, 64) BWD_CASE(8, 1, 100) BWD_CASE(8, 1, 128)
+      }
+    }
+    if (rc) return rc;
+  }
+  return PR_OK;
+}

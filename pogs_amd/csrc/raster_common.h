@@ -1,0 +1,102 @@
+// Shared pieces of the compositing kernels (forward and backward) for gfx950.
+//
+// Work decomposition: ONE WAVEFRONT owns one rectangular pixel region of one tile and walks that tile's
+// depth-sorted intersection list on its own -- no workgroup barrier anywhere.  A 16x16 tile is covered
+// by 1, 2 or 4 wavefronts (4, 2 or 1 pixels per lane); an 8x8 tile by one wavefront (1 pixel per lane).
+// Several pixels per lane amortise the per-Gaussian broadcast reads from LDS (the same 16 bytes
+// delivered to all lanes costs a full LDS cycle group) over 4x the FMAs, which is what keeps the loop
+// VALU-bound rather than LDS-bound.  Gaussians are staged 64 at a time (one per lane) into the
+// wavefront's private LDS slice; termination and "does anyone need this Gaussian" are wave ballots.
+#pragma once
+#include "common.h"
+
+namespace pr {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float ALPHA_MAX = 0.999f;
+constexpr float T_STOP = 1e-4f;
+
+// Pixel region owned by one wavefront, and the lane -> pixel map inside it.
+template <int TS, int PPL>
+struct Region;
+template <>
+struct Region<16, 4> {  // whole tile, lane = 2x2 quad
+  static constexpr int WPT = 1, BW = 2, BH = 2, LX = 8, RH = 16;
+};
+template <>
+struct Region<16, 2> {  // half tile (16x8), lane = 2x1 pair
+  static constexpr int WPT = 2, BW = 2, BH = 1, LX = 8, RH = 8;
+};
+template <>
+struct Region<16, 1> {  // quarter tile (16x4), lane = 1 pixel
+  static constexpr int WPT = 4, BW = 1, BH = 1, LX = 16, RH = 4;
+};
+template <>
+struct Region<8, 1> {  // whole 8x8 tile, lane = 1 pixel
+  static constexpr int WPT = 1, BW = 1, BH = 1, LX = 8, RH = 8;
+};
+
+// Bijective block-id remap: blocks that share an XCD (equal blockIdx % 8 under round-robin dispatch)
+// get a contiguous range of regions, so neighbouring tiles -- which share Gaussians -- hit one L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
+  unsigned q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+constexpr int round4(int x) { return (x + 3) & ~3; }
+// LDS row stride (floats) for staged colours; rows that are a multiple of 32 dwords would put every
+// lane's 16-byte store on the same banks.
+constexpr int color_row(int cd) { return round4(cd) % 32 == 0 ? round4(cd) + 4 : round4(cd); }
+
+template <int CD>
+struct alignas(16) WaveLds {
+  float4 g4[WAVE];              // x, y, opacity, A' (= -0.5 a log2e)
+  float2 g2[WAVE];              // B' (= -b log2e), C' (= -0.5 c log2e)
+  int32_t ids[WAVE];            // flat Gaussian index
+  float col[WAVE * color_row(CD)];
+  float red[round4(CD) + 16];   // backward: per-Gaussian totals on their way to the atomics
+};
+
+// Stage up to 64 intersections [first, first+count) of the sorted list: lane j loads Gaussian j.
+template <int CD>
+__device__ __forceinline__ void stage_batch(WaveLds<CD> &L, int lane, int first, int count,
+                                            const int32_t *__restrict__ flatten_ids,
+                                            const float *__restrict__ means2d, const float *__restrict__ conics,
+                                            const float *__restrict__ opacities, const float *__restrict__ colors,
+                                            int D, int ch_off) {
+  constexpr int ROW = color_row(CD);
+  if (lane < count) {
+    int g = flatten_ids[first + lane];
+    float2 xy = *reinterpret_cast<const float2 *>(means2d + 2 * (int64_t)g);
+    float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
+    float o = opacities[g];
+    L.g4[lane] = make_float4(xy.x, xy.y, o, -0.5f * LOG2E * ca);
+    L.g2[lane] = make_float2(-LOG2E * cb, -0.5f * LOG2E * cc);
+    L.ids[lane] = g;
+    const float *src = colors + (int64_t)g * D + ch_off;
+    int nch = D - ch_off;  // channels available from ch_off on
+    float *dst = L.col + lane * ROW;
+    if (((D | ch_off) & 3) == 0) {
+#pragma unroll
+      for (int k = 0; k < round4(CD); k += 4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < nch) v = *reinterpret_cast<const float4 *>(src + k);
+        *reinterpret_cast<float4 *>(dst + k) = v;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < round4(CD); k += 4) {
+        float4 v;
+        v.x = (k + 0 < nch) ? src[k + 0] : 0.f;
+        v.y = (k + 1 < nch) ? src[k + 1] : 0.f;
+        v.z = (k + 2 < nch) ? src[k + 2] : 0.f;
+        v.w = (k + 3 < nch) ? src[k + 3] : 0.f;
+        *reinterpret_cast<float4 *>(dst + k) = v;
+      }
+    }
+  }
+}
+
+}  // namespace pr

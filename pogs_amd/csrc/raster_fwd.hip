@@ -1,0 +1,204 @@
+// Forward compositing kernel for gfx950: per-tile front-to-back alpha blending.
+#include "raster_common.h"
+
+namespace pr {
+
+template <int TS, int PPL, int CD>
+__global__ void __launch_bounds__(256) raster_fwd_kernel(
+    int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
+    int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
+    const int32_t *__restrict__ flatten_ids, int n_isects, float *__restrict__ render_colors,
+    float *__restrict__ render_alphas, int32_t *__restrict__ last_ids) {
+  using Rg = Region<TS, PPL>;
+  constexpr int ROW = color_row(CD);
+  constexpr int CDP = round4(CD);
+  __shared__ WaveLds<CD> lds[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int region = (int)bid * 4 + wave;
+  if (region >= n_regions) return;
+  WaveLds<CD> &L = lds[wave];
+
+  const int tile_flat = region / Rg::WPT, sub = region % Rg::WPT;
+  const int n_tiles = tile_w * tile_h;
+  const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
+  const int ty = tile / tile_w, tx = tile % tile_w;
+  const int x0 = tx * TS + (lane % Rg::LX) * Rg::BW;
+  const int y0 = ty * TS + sub * Rg::RH + (lane / Rg::LX) * Rg::BH;
+  const int range_lo = isect_offsets[tile_flat];
+  const int range_hi = (tile_flat + 1 < n_regions / Rg::WPT) ? isect_offsets[tile_flat + 1] : n_isects;
+
+  float T[PPL], acc[PPL][CD];
+  int last[PPL];
+  bool done[PPL], inside[PPL];
+  const float px0 = (float)x0 + 0.5f, py0 = (float)y0 + 0.5f;
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    int x = x0 + (j % Rg::BW), y = y0 + (j / Rg::BW);
+    inside[j] = x < width && y < height;
+    done[j] = !inside[j];
+    T[j] = 1.f;
+    last[j] = range_lo;
+#pragma unroll
+    for (int k = 0; k < CD; ++k) acc[j][k] = 0.f;
+  }
+
+  bool all_done = false;
+  for (int first = range_lo; first < range_hi && !all_done; first += WAVE) {
+    const int count = min(WAVE, range_hi - first);
+    stage_batch<CD>(L, lane, first, count, flatten_ids, means2d, conics, opacities, colors, D, ch_off);
+    for (int t = 0; t < count; ++t) {
+      const float4 g = L.g4[t];
+      const float2 h = L.g2[t];
+      float vis[PPL];
+      bool any = false;
+      // shared partial products of the quadratic form over the lane's pixel block
+      float dx[Rg::BW], dy[Rg::BH], adx2[Rg::BW], cdy2[Rg::BH], bdx[Rg::BW];
+#pragma unroll
+      for (int i = 0; i < Rg::BW; ++i) {
+        dx[i] = g.x - (px0 + (float)i);
+        adx2[i] = g.w * dx[i] * dx[i];
+        bdx[i] = h.x * dx[i];
+      }
+#pragma unroll
+      for (int i = 0; i < Rg::BH; ++i) {
+        dy[i] = g.y - (py0 + (float)i);
+        cdy2[i] = h.y * dy[i] * dy[i];
+      }
+      bool all = true;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const int jx = j % Rg::BW, jy = j / Rg::BW;
+        const float power = adx2[jx] + cdy2[jy] + bdx[jx] * dy[jy];  // = -sigma * log2(e)
+        const float alpha = fminf(ALPHA_MAX, g.z * __builtin_amdgcn_exp2f(power));
+        const bool valid = (power <= 0.f) && (alpha >= ALPHA_MIN) && !done[j];
+        const float next_T = T[j] - alpha * T[j];
+        const bool stop = valid && (next_T <= T_STOP);
+        const bool contrib = valid && !stop;
+        done[j] = done[j] || stop;
+        vis[j] = contrib ? alpha * T[j] : 0.f;
+        T[j] = contrib ? next_T : T[j];
+        last[j] = contrib ? first + t + 1 : last[j];
+        any = any || contrib;
+        all = all && done[j];
+      }
+      if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+        const float4 *crow = reinterpret_cast<const float4 *>(L.col + t * ROW);
+#pragma unroll
+        for (int q = 0; q < CDP / 4; ++q) {
+          const float4 c = crow[q];
+          const float cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (4 * q + e < CD) {
+#pragma unroll
+              for (int j = 0; j < PPL; ++j) acc[j][4 * q + e] = fmaf(cv[e], vis[j], acc[j][4 * q + e]);
+            }
+          }
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(!all) == 0ull) {
+        all_done = true;
+        break;
+      }
+    }
+  }
+
+  const int nch = min(CD, D - ch_off);
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    if (!inside[j]) continue;
+    const int x = x0 + (j % Rg::BW), y = y0 + (j / Rg::BW);
+    const int64_t pix = ((int64_t)cam * height + y) * width + x;
+    float *out = render_colors + pix * D + ch_off;
+    if (backgrounds) {
+      const float *bg = backgrounds + (int64_t)cam * D + ch_off;
+#pragma unroll
+      for (int k = 0; k < CD; ++k)
+        if (k < nch) acc[j][k] = fmaf(T[j], bg[k], acc[j][k]);
+    }
+    if (((D | ch_off) & 3) == 0) {
+#pragma unroll
+      for (int k = 0; k + 3 < CD; k += 4)
+        if (k < nch) *reinterpret_cast<float4 *>(out + k) = make_float4(acc[j][k], acc[j][k + 1], acc[j][k + 2], acc[j][k + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < CD; ++k)
+        if (k < nch) out[k] = acc[j][k];
+    }
+    if (ch_off == 0) {
+      render_alphas[pix] = 1.f - T[j];
+      last_ids[pix] = last[j];
+    }
+  }
+}
+
+template <int TS, int PPL, int CD>
+static int launch_fwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const float *colors,
+                      const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
+                      const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects, float *render_colors,
+                      float *render_alphas, int32_t *last_ids, hipStream_t stream) {
+  const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
+  const unsigned grid = (unsigned)((n_regions + 3) / 4);
+  hipLaunchKernelGGL((raster_fwd_kernel<TS, PPL, CD>), dim3(grid), dim3(256), 0, stream, (int)n_regions, N, D, ch_off,
+                     means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
+                     flatten_ids, (int)n_isects, render_colors, render_alphas, last_ids);
+  return check_launch("raster_fwd_kernel");
+}
+
+// Channel-chunk widths with a compiled kernel.
+static const int kChunks[] = {4, 8, 16, 24, 32, 36, 40, 48};
+constexpr int kMaxChunk = 48;
+
+static int pick_chunk(int want) {
+  for (int c : kChunks)
+    if (c >= want) return c;
+  return kMaxChunk;
+}
+
+}  // namespace pr
+
+using namespace pr;
+
+#define FWD_CASE(TS, PPL, CDV)                                                                                        \
+  case CDV:                                                                                                           \
+    rc = launch_fwd<TS, PPL, CDV>(C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height,       \
+                                  tile_w, tile_h, isect_offsets, flatten_ids, n_isects, render_colors, render_alphas, \
+                                  last_ids, (hipStream_t)stream);                                                     \
+    break;
+
+extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
+                             const float *opacities, const float *backgrounds, int width, int height, int tile_size,
+                             int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
+                             int64_t n_isects, float *render_colors, float *render_alphas, int32_t *last_ids,
+                             void *stream) {
+  if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)
+    return PR_EINVAL;
+  if (tile_size != 16 && tile_size != 8) return PR_EUNSUPPORTED;
+  if (D > pr_max_channels() || n_isects > 2147483647ll) return PR_EUNSUPPORTED;
+  if ((int64_t)tile_w * tile_size < width || (int64_t)tile_h * tile_size < height) return PR_EINVAL;
+  if (C == 0) return PR_OK;
+  if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return PR_EINVAL;
+  if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return PR_EINVAL;
+  if ((int64_t)C * tile_w * tile_h * 4 > 2147483647ll) return PR_EUNSUPPORTED;
+  const int n_chunks = (D + kMaxChunk - 1) / kMaxChunk;
+  const int per = ((D + n_chunks - 1) / n_chunks + 3) & ~3;
+  for (int off = 0; off < D; off += per) {
+    const int cd = pick_chunk(min(per, D - off));
+    int rc = PR_EUNSUPPORTED;
+    if (tile_size == 16) {
+      switch (cd) {
+        FWD_CASE(16, 4, 4) FWD_CASE(16, 4, 8) FWD_CASE(16, 4, 16) FWD_CASE(16, 4, 24) FWD_CASE(16, 4, 32)
+        FWD_CASE(16, 4, 36) FWD_CASE(16, 4, 40) FWD_CASE(16, 4, 48)
+      }
+    } else {
+      switch (cd) {
+        FWD_CASE(8, 1, 4) FWD_CASE(8, 1, 8) FWD_CASE(8, 1, 16) FWD_CASE(8, 1, 24) FWD_CASE(8, 1, 32)
+        FWD_CASE(8, 1, 36) FWD_CASE(8, 1, 40) FWD_CASE(8, 1, 48)
+      }
+    }
+    if (rc) return rc;
+  }
+  return PR_OK;
+}

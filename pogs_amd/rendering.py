@@ -1,0 +1,402 @@
+"""Drop-in for ``gsplat.rendering.rasterization`` on MI355X.
+
+Mirrors the call the reference makes at ``pogs/pogs.py:352-371`` (RGB / RGB+ED with SH),
+``pogs/pogs.py:419-437`` (96-channel features, absgrad), ``pogs/pogs.py:493-510`` (64-channel
+features) and ``pogs/pogs.py:930-948`` (no-grad features): same argument names and meaning, same
+``(render_colors, render_alphas, meta)`` return, same ``meta`` keys (gsplat 1.4.0), same error
+behaviour for malformed shapes (``AssertionError``).  All device work goes through the C ABI of
+``libpogs_rast.so``; there is no PyTorch fallback.
+
+One extension beyond gsplat: ``features=[N,F]`` composites F extra per-Gaussian channels in the SAME
+pass as the SH colours (output channels ``[rgb | features | depth]``), so an RGB + feature render
+costs one projection, one binning and one walk over the tile lists instead of two of each.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows(t: Tensor, width: int) -> Tuple[Tensor, int]:
+    """Return (tensor, row stride in floats) for a [..., width] float32 tensor whose rows may be strided
+    (e.g. a column slice of a packed buffer); copies only when the layout is not row-regular."""
+    flat_ok = t.stride(-1) == 1 and t.dim() >= 2
+    if flat_ok:
+        ld = t.stride(-2)
+        ok = ld >= width
+        for d in range(t.dim() - 3, -1, -1):
+            ok = ok and t.stride(d) == t.stride(d + 1) * t.shape[d + 1]
+        if ok:
+            return t, ld
+    t = t.contiguous()
+    return t, width
+
+
+def _check_device(*ts: Optional[Tensor]) -> torch.device:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("pogs_amd.rasterization needs tensors on a HIP device (no CPU fallback)")
+        if t.dtype != torch.float32:
+            raise RuntimeError("pogs_amd.rasterization computes in float32")
+        dev = t.device if dev is None else dev
+        if t.device != dev:
+            raise RuntimeError("all tensors must live on the same device")
+    return dev
+
+
+class _Projection(torch.autograd.Function):
+    """EWA projection; stands in for gsplat ``fully_fused_projection`` (non-packed)."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                radius_clip, calc_compensations):
+        lib = _lib.load()
+        C, N = viewmats.shape[0], means.shape[0]
+        means, quats, scales = means.contiguous(), quats.contiguous(), scales.contiguous()
+        viewmats, Ks = viewmats.contiguous(), Ks.contiguous()
+        dev = means.device
+        radii = torch.empty(C, N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(C, N, dtype=torch.float32, device=dev)
+        conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        comps = torch.empty(C, N, dtype=torch.float32, device=dev) if calc_compensations else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.pr_project_fwd(C, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(viewmats), _ptr(Ks),
+                                          width, height, eps2d, near_plane, far_plane, radius_clip, _ptr(radii),
+                                          _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(comps), _stream()),
+                       "pr_project_fwd")
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii)
+        ctx.args = (width, height, eps2d)
+        ctx.mark_non_differentiable(radii)
+        return radii, means2d, depths, conics, comps
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps):
+        lib = _lib.load()
+        means, quats, scales, viewmats, Ks, radii = ctx.saved_tensors
+        width, height, eps2d = ctx.args
+        C, N = radii.shape
+        dev = means.device
+        if v_means2d is None:
+            v_means2d = torch.zeros(C, N, 2, dtype=torch.float32, device=dev)
+        if v_conics is None:
+            v_conics = torch.zeros(C, N, 3, dtype=torch.float32, device=dev)
+        v_means2d, ld_m = _rows(v_means2d, 2)
+        v_conics, ld_c = _rows(v_conics, 3)
+        v_depths = None if v_depths is None else v_depths.contiguous()
+        v_comps = None if v_comps is None else v_comps.contiguous()
+        v_means = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        v_quats = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        v_scales = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        v_viewmats = torch.zeros(C, 4, 4, dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.pr_project_bwd(C, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(viewmats), _ptr(Ks),
+                                          width, height, eps2d, _ptr(radii), _ptr(v_means2d), ld_m, _ptr(v_depths),
+                                          _ptr(v_conics), ld_c, _ptr(v_comps), _ptr(v_means), _ptr(v_quats),
+                                          _ptr(v_scales), _ptr(v_viewmats), _stream()), "pr_project_bwd")
+        return (v_means if ctx.needs_input_grad[0] else None, v_quats if ctx.needs_input_grad[1] else None,
+                v_scales if ctx.needs_input_grad[2] else None, v_viewmats, None, None, None, None, None, None,
+                None, None)
+
+
+class _SphericalHarmonics(torch.autograd.Function):
+    """View-dependent colour; stands in for gsplat ``spherical_harmonics`` fused with the caller's
+    ``clamp_min(. + 0.5, 0)``."""
+
+    @staticmethod
+    def forward(ctx, degree, means, campos, coeffs, radii, post):
+        lib = _lib.load()
+        C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1]
+        means, campos, coeffs = means.contiguous(), campos.contiguous(), coeffs.contiguous()
+        colors = torch.empty(C, N, 3, dtype=torch.float32, device=means.device)
+        with torch.cuda.device(means.device):
+            _lib.check(lib.pr_sh_fwd(C, N, K, degree, _ptr(means), _ptr(campos), _ptr(coeffs), _ptr(radii),
+                                     int(post), _ptr(colors), 3, _stream()), "pr_sh_fwd")
+        ctx.save_for_backward(means, campos, coeffs, radii)
+        ctx.args = (degree, int(post))
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        lib = _lib.load()
+        means, campos, coeffs, radii = ctx.saved_tensors
+        degree, post = ctx.args
+        C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1]
+        dev = means.device
+        v_colors, ld = _rows(v_colors, 3)
+        v_coeffs = torch.empty(N, K, 3, dtype=torch.float32, device=dev)
+        v_means = torch.empty(N, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        v_campos = torch.zeros(C, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.pr_sh_bwd(C, N, K, degree, _ptr(means), _ptr(campos), _ptr(coeffs), _ptr(radii), post,
+                                     _ptr(v_colors), ld, _ptr(v_coeffs), _ptr(v_means), _ptr(v_campos), _stream()),
+                       "pr_sh_bwd")
+        return None, v_means, v_campos, (v_coeffs if ctx.needs_input_grad[3] else None), None, None
+
+
+def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
+                tile_height: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """Stands in for gsplat ``isect_tiles`` (non-packed, sorted).  means2d [C,N,2], radii [C,N] int32,
+    depths [C,N] -> tiles_per_gauss [C,N] int32, isect_ids [I] int64 (sorted), flatten_ids [I] int32."""
+    lib = _lib.load()
+    C, N = radii.shape
+    dev = means2d.device
+    means2d, radii, depths = means2d.detach().contiguous(), radii.contiguous(), depths.detach().contiguous()
+    tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
+    if C * N == 0:
+        return (tiles_per_gauss, torch.empty(0, dtype=torch.int64, device=dev),
+                torch.empty(0, dtype=torch.int32, device=dev))
+    cum = torch.empty(C * N, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        nb = lib.pr_isect_count_scratch_bytes(C, N)
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _lib.check(lib.pr_isect_count(C, N, _ptr(means2d), _ptr(radii), tile_size, tile_width, tile_height,
+                                      _ptr(tiles_per_gauss), _ptr(cum), _ptr(scratch), nb, _stream()),
+                   "pr_isect_count")
+        n_isects = int(cum[-1].item())  # the path's one device->host read
+        isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
+        flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
+        if n_isects > 0:
+            nb = lib.pr_isect_sort_scratch_bytes(C, N, n_isects)
+            scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+            _lib.check(lib.pr_isect_emit_sort(C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(cum), tile_size,
+                                              tile_width, tile_height, n_isects, _ptr(isect_ids), _ptr(flatten_ids),
+                                              _ptr(scratch), nb, _stream()), "pr_isect_emit_sort")
+    return tiles_per_gauss, isect_ids, flatten_ids
+
+
+def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
+    """Stands in for gsplat ``isect_offset_encode``: int32 [C, tile_height, tile_width]."""
+    lib = _lib.load()
+    dev = isect_ids.device
+    offsets = torch.empty(n_cameras, tile_height, tile_width, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.pr_isect_offsets(isect_ids.numel(), _ptr(isect_ids.contiguous()), n_cameras, tile_width,
+                                        tile_height, _ptr(offsets), _stream()), "pr_isect_offsets")
+    return offsets
+
+
+class _Rasterize(torch.autograd.Function):
+    """Tile compositing; stands in for gsplat ``rasterize_to_pixels``."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size, isect_offsets,
+                flatten_ids, absgrad):
+        lib = _lib.load()
+        C, N, D = colors.shape
+        dev = means2d.device
+        means2d_c, conics, colors, opacities = (means2d.contiguous(), conics.contiguous(), colors.contiguous(),
+                                                opacities.contiguous())
+        backgrounds = None if backgrounds is None else backgrounds.contiguous()
+        th, tw = isect_offsets.shape[1:]
+        render_colors = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
+        render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.pr_raster_fwd(C, N, D, _ptr(means2d_c), _ptr(conics), _ptr(colors), _ptr(opacities),
+                                         _ptr(backgrounds), width, height, tile_size, tw, th, _ptr(isect_offsets),
+                                         _ptr(flatten_ids), flatten_ids.numel(), _ptr(render_colors),
+                                         _ptr(render_alphas), _ptr(last_ids), _stream()), "pr_raster_fwd")
+        ctx.save_for_backward(means2d_c, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids,
+                              render_alphas, last_ids)
+        ctx.args = (width, height, tile_size, absgrad)
+        ctx.means2d_obj = means2d  # the object callers hold in meta["means2d"]; receives .absgrad
+        return render_colors, render_alphas
+
+    @staticmethod
+    def backward(ctx, v_render_colors, v_render_alphas):
+        lib = _lib.load()
+        (means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, render_alphas,
+         last_ids) = ctx.saved_tensors
+        width, height, tile_size, absgrad = ctx.args
+        C, N, D = colors.shape
+        dev = means2d.device
+        th, tw = isect_offsets.shape[1:]
+        if v_render_colors is None:
+            v_render_colors = torch.zeros(C, height, width, D, dtype=torch.float32, device=dev)
+        if v_render_alphas is None:
+            v_render_alphas = torch.zeros(C, height, width, 1, dtype=torch.float32, device=dev)
+        v_render_colors, v_render_alphas = v_render_colors.contiguous(), v_render_alphas.contiguous()
+        geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+        want_colors = ctx.needs_input_grad[2]
+        v_geom = torch.zeros(C * N, 8, dtype=torch.float32, device=dev) if geom else None
+        v_colors = torch.zeros(C, N, D, dtype=torch.float32, device=dev) if want_colors else None
+        if geom or want_colors:
+            with torch.cuda.device(dev):
+                _lib.check(lib.pr_raster_bwd(C, N, D, _ptr(means2d), _ptr(conics), _ptr(colors), _ptr(opacities),
+                                             _ptr(backgrounds), width, height, tile_size, tw, th,
+                                             _ptr(isect_offsets), _ptr(flatten_ids), flatten_ids.numel(),
+                                             _ptr(render_alphas), _ptr(last_ids), _ptr(v_render_colors),
+                                             _ptr(v_render_alphas), int(absgrad), int(geom), _ptr(v_geom),
+                                             _ptr(v_colors), _stream()), "pr_raster_bwd")
+        v_means2d = v_conics = v_opacities = None
+        if geom:
+            g = v_geom.view(C, N, 8)
+            v_means2d, v_conics, v_opacities = g[..., 0:2], g[..., 2:5], g[..., 5]
+            if absgrad:
+                ctx.means2d_obj.absgrad = g[..., 6:8]
+        v_backgrounds = None
+        if backgrounds is not None and ctx.needs_input_grad[4]:
+            v_backgrounds = (v_render_colors * (1.0 - render_alphas)).sum(dim=(1, 2))
+        ctx.means2d_obj = None
+        return (v_means2d if ctx.needs_input_grad[0] else None, v_conics if ctx.needs_input_grad[1] else None,
+                v_colors, v_opacities if ctx.needs_input_grad[3] else None, v_backgrounds, None, None, None, None,
+                None, None)
+
+
+def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor, image_width: int,
+                        image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
+                        backgrounds: Optional[Tensor] = None, absgrad: bool = False) -> Tuple[Tensor, Tensor]:
+    """Stands in for gsplat ``rasterize_to_pixels`` (non-packed): [C,N,*] inputs ->
+    render_colors [C,H,W,D], render_alphas [C,H,W,1]."""
+    return _Rasterize.apply(means2d, conics, colors, opacities, backgrounds, image_width, image_height, tile_size,
+                            isect_offsets, flatten_ids, absgrad)
+
+
+def fully_fused_projection(means, quats, scales, viewmats, Ks, width, height, eps2d=0.3, near_plane=0.01,
+                           far_plane=1e10, radius_clip=0.0, calc_compensations=False):
+    """Stands in for gsplat ``fully_fused_projection`` (non-packed, quats+scales form)."""
+    return _Projection.apply(means, quats, scales, viewmats, Ks, int(width), int(height), float(eps2d),
+                             float(near_plane), float(far_plane), float(radius_clip), bool(calc_compensations))
+
+
+class _CameraCenters(torch.autograd.Function):
+    """c = inverse(V)[:, :3, 3] for rigid world->camera matrices V.  Forward uses the closed form -R^T t;
+    backward is the derivative of the general matrix inverse, dM = -M dV M, so gradients equal those of
+    ``torch.inverse(viewmats)[:, :3, 3]`` (what gsplat's ``rasterization`` differentiates through)."""
+
+    @staticmethod
+    def forward(ctx, viewmats):
+        R = viewmats[:, :3, :3]
+        t = viewmats[:, :3, 3:4]
+        M = torch.zeros_like(viewmats)
+        M[:, :3, :3] = R.transpose(1, 2)
+        M[:, :3, 3:4] = -(R.transpose(1, 2) @ t)
+        M[:, 3, 3] = 1.0
+        ctx.save_for_backward(M)
+        return M[:, :3, 3].clone()
+
+    @staticmethod
+    def backward(ctx, v_c):
+        (M,) = ctx.saved_tensors
+        v_M = torch.zeros_like(M)
+        v_M[:, :3, 3] = v_c
+        Mt = M.transpose(1, 2)
+        return -(Mt @ v_M @ Mt)
+
+
+def camera_centers(viewmats: Tensor) -> Tensor:
+    """World-space camera centres of rigid world->camera matrices (the matrices ``get_viewmat`` builds,
+    ``pogs/pogs.py:75-90``)."""
+    return _CameraCenters.apply(viewmats)
+
+
+def rasterization(
+    means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor, viewmats: Tensor, Ks: Tensor,
+    width: int, height: int, near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0,
+    eps2d: float = 0.3, sh_degree: Optional[int] = None, packed: bool = True, tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None, render_mode: str = "RGB", sparse_grad: bool = False,
+    absgrad: bool = False, rasterize_mode: str = "classic", channel_chunk: int = 32, distributed: bool = False,
+    camera_model: str = "pinhole", covars: Optional[Tensor] = None, features: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Dict]:
+    """Rasterize N 3-D Gaussians to C images; gsplat 1.4.0 ``rasterization`` signature.
+
+    Supported configuration = the one POGS uses: dense (``packed`` is accepted and ignored: results and
+    ``meta`` are always in the non-packed [C,N,...] layout the reference requests with ``packed=False``),
+    ``sparse_grad=False``, ``distributed=False``, pinhole cameras, quats+scales (``covars=None``).
+    ``channel_chunk`` is accepted for signature compatibility; channel tiling is chosen inside the library.
+    """
+    N = means.shape[0]
+    C = viewmats.shape[0]
+    assert means.shape == (N, 3), means.shape
+    assert quats.shape == (N, 4), quats.shape
+    assert scales.shape == (N, 3), scales.shape
+    assert opacities.shape == (N,), opacities.shape
+    assert viewmats.shape == (C, 4, 4), viewmats.shape
+    assert Ks.shape == (C, 3, 3), Ks.shape
+    assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
+    assert rasterize_mode in ["classic", "antialiased"], rasterize_mode
+    if covars is not None:
+        raise NotImplementedError("covars input is outside the POGS path (quats+scales only)")
+    if sparse_grad or distributed:
+        raise NotImplementedError("sparse_grad / distributed modes are outside the POGS path")
+    if camera_model != "pinhole":
+        raise NotImplementedError("only pinhole cameras are on the POGS path")
+    if sh_degree is None:
+        assert (colors.dim() == 2 and colors.shape[0] == N) or (
+            colors.dim() == 3 and colors.shape[:2] == (C, N)), colors.shape
+    else:
+        assert (colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3) or (
+            colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
+        assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
+    if backgrounds is not None:
+        assert backgrounds.dim() == 2 and backgrounds.shape[0] == C, backgrounds.shape
+    _check_device(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, features)
+    width, height = int(width), int(height)
+
+    radii, means2d, depths, conics, compensations = fully_fused_projection(
+        means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
+        calc_compensations=(rasterize_mode == "antialiased"))
+    opac = opacities[None, :].expand(C, N)
+    if compensations is not None:
+        opac = opac * compensations
+
+    if sh_degree is None:
+        cols = colors[None].expand(C, -1, -1) if colors.dim() == 2 else colors
+    else:
+        if colors.dim() == 4:
+            if C != 1:
+                raise NotImplementedError("per-camera SH coefficients with C > 1")
+            colors = colors[0]
+        cols = _SphericalHarmonics.apply(int(sh_degree), means, camera_centers(viewmats), colors, radii, True)
+    if features is not None:
+        assert features.dim() == 2 and features.shape[0] == N, features.shape
+        cols = torch.cat([cols, features[None].expand(C, -1, -1)], dim=-1)
+    bgs = backgrounds
+    if render_mode in ("RGB+D", "RGB+ED"):
+        cols = torch.cat([cols, depths[..., None]], dim=-1)
+        if bgs is not None:
+            bgs = torch.cat([bgs, torch.zeros(C, 1, device=bgs.device, dtype=bgs.dtype)], dim=-1)
+    elif render_mode in ("D", "ED"):
+        cols = depths[..., None]
+        if bgs is not None:
+            bgs = torch.zeros(C, 1, device=bgs.device, dtype=bgs.dtype)
+    if bgs is not None:
+        assert bgs.shape == (C, cols.shape[-1]), bgs.shape
+
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height)
+    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
+
+    render_colors, render_alphas = rasterize_to_pixels(
+        means2d, conics, cols, opac, width, height, tile_size, isect_offsets, flatten_ids, backgrounds=bgs,
+        absgrad=absgrad)
+    if render_mode in ("ED", "RGB+ED"):
+        render_colors = torch.cat(
+            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
+
+    meta = {
+        "camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths,
+        "conics": conics, "opacities": opac, "tile_width": tile_width, "tile_height": tile_height,
+        "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids, "flatten_ids": flatten_ids,
+        "isect_offsets": isect_offsets, "width": width, "height": height, "tile_size": tile_size,
+        "n_cameras": C,
+    }
+    return render_colors, render_alphas, meta

@@ -1,0 +1,67 @@
+"""Helpers shared by the parity tests: small seeded scenes and the comparison rules.
+
+Comparison rules (the bar of the north star):
+  * tile counts, intersection ids, sort order, offsets: bit-exact;
+  * colour / alpha / features: max-abs error <= 1e-4 on every pixel that is not within a hair of one of
+    the compositing discontinuities (the oracle flags those, see ``oracle.gsplat_ref._composite``);
+    flagged pixels must stay a tiny fraction and within the size of one skipped contribution;
+  * gradients: elementwise |d| <= 1e-3 |ref| + 1e-4 max|ref|  (1e-3 relative).
+"""
+import torch
+
+from pogs_amd.scenes import make_scene
+
+IMG_TOL = 1e-4
+GRAD_RTOL = 1e-3
+
+
+def small_scene(n=300, w=64, h=48, f=5, views=1, seed=1, lo=0.02, hi=0.25):
+    return make_scene(n, w, h, n_features=f, n_views=views, seed=seed, scale_lo=lo, scale_hi=hi)
+
+
+def scene_args(sc, dtype=torch.float32, device="cpu", requires_grad=False):
+    a = dict(
+        means=sc.means, quats=sc.quats, scales=sc.log_scales.exp(), opacities=torch.sigmoid(sc.opacity_logits),
+        colors=sc.sh, viewmats=sc.viewmats, Ks=sc.Ks, features=sc.features)
+    out = {}
+    for k, v in a.items():
+        t = v.to(dtype).to(device).contiguous()
+        if requires_grad and k not in ("Ks",):
+            t.requires_grad_(True)
+        out[k] = t
+    out["width"], out["height"] = sc.width, sc.height
+    return out
+
+
+def assert_grad_close(got, ref, name, rtol=GRAD_RTOL, atol_frac=1e-4):
+    if ref is None:  # the oracle's graph does not reach this input: the gradient is identically zero
+        assert got is None or got.abs().max().item() == 0, name
+        return
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = ref.abs().max().item()
+    if scale == 0:
+        assert got.abs().max().item() == 0, name
+        return
+    err = (got - ref).abs()
+    bound = rtol * ref.abs() + atol_frac * scale
+    bad = err > bound
+    assert not bad.any(), (
+        f"{name}: {int(bad.sum())}/{bad.numel()} elements off; max err {err.max().item():.3e} "
+        f"(scale {scale:.3e}, worst ratio {(err / bound).max().item():.2f})")
+
+
+def assert_image_close(got, ref, ambiguous, name, tol=IMG_TOL):
+    """got/ref [C,H,W,D]; ambiguous [C,H,W] bool."""
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    err = (got - ref).abs().amax(dim=-1)
+    clean = ~ambiguous
+    worst = err[clean].max().item() if clean.any() else 0.0
+    assert worst <= tol, f"{name}: max abs err {worst:.3e} > {tol} on unflagged pixels"
+    frac = ambiguous.float().mean().item()
+    assert frac <= 0.02, f"{name}: {frac:.3%} of pixels flagged ambiguous"
+    if ambiguous.any():
+        scale = max(1.0, ref.abs().max().item())
+        assert err[ambiguous].max().item() <= 2e-2 * scale, f"{name}: flagged pixel off by more than one splat"

@@ -1,0 +1,343 @@
+"""GPU parity tests: every stage of the HIP path (through the C ABI) against the CPU oracle.
+
+Run on the GPU box with ``python -m pytest tests -m gpu``.  The oracle is only the checker here.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import gsplat_ref as R
+from tests._util import assert_grad_close, assert_image_close, scene_args, small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _rendering():
+    from pogs_amd import rendering
+
+    return rendering
+
+
+def _cpu64(t):
+    return t.detach().double().cpu()
+
+
+# ------------------------------------------------------------------------------------------------
+# projection
+# ------------------------------------------------------------------------------------------------
+def _edge_scene():
+    """Scene with Gaussians behind the camera, beyond the image border and straddling it."""
+    sc = small_scene(n=400, w=70, h=45, views=2, seed=3)
+    sc.means[:40, 2] -= 4.5          # behind / at the view-0 camera
+    sc.means[40:80, 0] *= 6.0         # far off to the sides
+    sc.means[80:100, 1] += 1.4        # straddling the bottom border
+    return sc
+
+
+@pytest.mark.parametrize("antialiased", [False, True])
+def test_projection_forward(gpu, antialiased):
+    rd = _rendering()
+    sc = _edge_scene()
+    a = scene_args(sc, device=gpu)
+    radii, means2d, depths, conics, comps = rd.fully_fused_projection(
+        a["means"], a["quats"], a["scales"], a["viewmats"], a["Ks"], sc.width, sc.height,
+        calc_compensations=antialiased)
+    b = scene_args(sc, dtype=torch.float64)
+    r_ref, m_ref, d_ref, c_ref, k_ref = R.fully_fused_projection(
+        b["means"], b["quats"], b["scales"], b["viewmats"], b["Ks"], sc.width, sc.height,
+        calc_compensations=antialiased)
+    radii_c = radii.cpu()
+    diff = (radii_c - r_ref).abs()
+    assert diff.max().item() <= 1, "radius off by more than one pixel"
+    assert (diff > 0).float().mean().item() < 0.01, "too many radius mismatches"
+    assert (r_ref == 0).sum() > 50 and (r_ref > 0).sum() > 200  # the scene exercises both branches
+    vis = (radii_c > 0) & (r_ref > 0)
+    assert torch.allclose(_cpu64(means2d)[vis], m_ref[vis], rtol=1e-5, atol=2e-3)
+    assert torch.allclose(_cpu64(depths)[vis], d_ref[vis], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(_cpu64(conics)[vis], c_ref[vis], rtol=2e-4, atol=1e-6)
+    if antialiased:
+        assert torch.allclose(_cpu64(comps)[vis], k_ref[vis], rtol=2e-4, atol=1e-6)
+    # culled entries are written as zeros
+    assert _cpu64(conics)[radii_c == 0].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("antialiased", [False, True])
+def test_projection_backward(gpu, antialiased):
+    rd = _rendering()
+    sc = _edge_scene()
+    a = scene_args(sc, device=gpu, requires_grad=True)
+    radii, means2d, depths, conics, comps = rd.fully_fused_projection(
+        a["means"], a["quats"], a["scales"], a["viewmats"], a["Ks"], sc.width, sc.height,
+        calc_compensations=antialiased)
+    g = torch.Generator().manual_seed(7)
+    vm, vd, vc = (torch.randn(means2d.shape, generator=g), torch.randn(depths.shape, generator=g),
+                  torch.randn(conics.shape, generator=g))
+    vk = torch.randn(depths.shape, generator=g)
+    loss = (means2d * vm.to(gpu)).sum() + (depths * vd.to(gpu)).sum() + (conics * vc.to(gpu)).sum()
+    if antialiased:
+        loss = loss + (comps * vk.to(gpu)).sum()
+    loss.backward()
+
+    b = scene_args(sc, dtype=torch.float64, requires_grad=True)
+    r2, m2, d2, c2, k2 = R.fully_fused_projection(
+        b["means"], b["quats"], b["scales"], b["viewmats"], b["Ks"], sc.width, sc.height,
+        calc_compensations=antialiased, radii_override=radii.cpu())
+    mask = (radii.cpu() > 0).double()
+    lref = (m2 * vm.double() * mask[..., None]).sum() + (d2 * vd.double() * mask).sum() \
+        + (c2 * vc.double() * mask[..., None]).sum()
+    if antialiased:
+        lref = lref + (k2 * vk.double() * mask).sum()
+    lref.backward()
+    for k in ("means", "quats", "scales"):
+        assert_grad_close(a[k].grad, b[k].grad, k)
+    assert_grad_close(a["viewmats"].grad[:, :3, :], b["viewmats"].grad[:, :3, :], "viewmats")
+
+
+# ------------------------------------------------------------------------------------------------
+# spherical harmonics
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+def test_spherical_harmonics(gpu, degree):
+    rd = _rendering()
+    sc = small_scene(n=257, views=2, seed=5)
+    g = torch.Generator().manual_seed(11)
+    radii = (torch.rand(2, sc.n, generator=g) > 0.2).int()
+    sh = sc.sh.clone()
+    sh[:, 0, :] -= 1.0  # push some colours below the clamp
+    means = sc.means.to(gpu).requires_grad_(True)
+    coeffs = sh.to(gpu).requires_grad_(True)
+    viewmats = sc.viewmats.to(gpu).requires_grad_(True)
+    cols = rd._SphericalHarmonics.apply(degree, means, rd.camera_centers(viewmats), coeffs, radii.to(gpu), True)
+    v = torch.randn(cols.shape, generator=g)
+    (cols * v.to(gpu)).sum().backward()
+
+    m64 = sc.means.double().requires_grad_(True)
+    c64 = sh.double().requires_grad_(True)
+    v64 = sc.viewmats.double().requires_grad_(True)
+    dirs = m64[None] - torch.inverse(v64)[:, None, :3, 3]
+    ref = R.spherical_harmonics(degree, dirs, c64[None].expand(2, -1, -1, -1), masks=radii > 0)
+    ref = torch.clamp_min(ref + 0.5, 0.0)
+    (ref * v.double()).sum().backward()
+    assert (ref == 0).sum() > 10 and (ref > 0).sum() > 100
+    assert torch.allclose(_cpu64(cols), ref, rtol=1e-5, atol=2e-6)
+    assert_grad_close(coeffs.grad, c64.grad, "sh coeffs")
+    assert_grad_close(means.grad, m64.grad, "means via view direction")
+    if degree > 0:
+        assert_grad_close(viewmats.grad[:, :3, :], v64.grad[:, :3, :], "viewmats via camera centre")
+
+
+# ------------------------------------------------------------------------------------------------
+# binning: bit-exact
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile_size", [8, 16])
+@pytest.mark.parametrize("views", [1, 3])
+def test_isect_bit_exact(gpu, tile_size, views):
+    rd = _rendering()
+    sc = small_scene(n=1500, w=150, h=90, views=views, seed=2, lo=0.01, hi=0.3)
+    # exact depth ties across different Gaussians: ties must resolve by ascending flat index
+    sc.means[100:200] = sc.means[0:100]
+    a = scene_args(sc, device=gpu)
+    radii, means2d, depths, conics, _ = rd.fully_fused_projection(
+        a["means"], a["quats"], a["scales"], a["viewmats"], a["Ks"], sc.width, sc.height)
+    tw, th = math.ceil(sc.width / tile_size), math.ceil(sc.height / tile_size)
+    tpg, ids, flat = rd.isect_tiles(means2d, radii, depths, tile_size, tw, th)
+    offs = rd.isect_offset_encode(ids, views, tw, th)
+    tpg_r, ids_r, flat_r = R.isect_tiles(means2d.cpu(), radii.cpu(), depths.cpu(), tile_size, tw, th)
+    offs_r = R.isect_offset_encode(ids_r, views, tw, th)
+    assert ids_r.numel() > 5000
+    assert torch.equal(tpg.cpu(), tpg_r)
+    assert torch.equal(ids.cpu(), ids_r)
+    assert torch.equal(flat.cpu(), flat_r)
+    assert torch.equal(offs.cpu(), offs_r)
+    assert ids.dtype == torch.int64 and flat.dtype == torch.int32 and offs.dtype == torch.int32
+
+
+def test_isect_empty(gpu):
+    rd = _rendering()
+    means2d = torch.zeros(1, 10, 2, device=gpu)
+    radii = torch.zeros(1, 10, dtype=torch.int32, device=gpu)
+    depths = torch.ones(1, 10, device=gpu)
+    tpg, ids, flat = rd.isect_tiles(means2d, radii, depths, 16, 4, 3)
+    offs = rd.isect_offset_encode(ids, 1, 4, 3)
+    assert ids.numel() == 0 and flat.numel() == 0 and int(tpg.sum()) == 0
+    assert offs.shape == (1, 3, 4) and int(offs.abs().sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# compositing
+# ------------------------------------------------------------------------------------------------
+def _staged(gpu, sc, D, tile_size, seed=0):
+    """Project + bin on the GPU, return (device tensors, CPU float64 copies) for a D-channel raster call."""
+    rd = _rendering()
+    a = scene_args(sc, device=gpu)
+    C = sc.viewmats.shape[0]
+    radii, means2d, depths, conics, _ = rd.fully_fused_projection(
+        a["means"], a["quats"], a["scales"], a["viewmats"], a["Ks"], sc.width, sc.height)
+    tw, th = math.ceil(sc.width / tile_size), math.ceil(sc.height / tile_size)
+    _, ids, flat = rd.isect_tiles(means2d, radii, depths, tile_size, tw, th)
+    offs = rd.isect_offset_encode(ids, C, tw, th)
+    g = torch.Generator().manual_seed(seed)
+    colors = torch.randn(C, sc.n, D, generator=g)
+    opac = a["opacities"][None].expand(C, -1).contiguous()
+    dev = dict(means2d=means2d.detach(), conics=conics.detach(), colors=colors.to(gpu), opacities=opac)
+    return dev, offs, flat
+
+
+def _oracle_raster(dev, offs, flat, sc, tile_size, bg, need_grad):
+    cpu = {k: v.detach().double().cpu().requires_grad_(need_grad) for k, v in dev.items()}
+    out, alpha, amb = R.rasterize_to_pixels(
+        cpu["means2d"], cpu["conics"], cpu["colors"], cpu["opacities"], sc.width, sc.height, tile_size,
+        offs.cpu(), flat.cpu(), backgrounds=None if bg is None else bg.double().cpu(), return_ambiguous=True)
+    return cpu, out, alpha, amb
+
+
+@pytest.mark.parametrize("tile_size,D", [(16, 3), (16, 4), (16, 8), (16, 19), (16, 36), (16, 65), (16, 97),
+                                         (8, 4), (8, 19), (8, 64)])
+@pytest.mark.parametrize("with_bg", [False, True])
+def test_raster_forward(gpu, tile_size, D, with_bg):
+    rd = _rendering()
+    sc = small_scene(n=600, w=70, h=45, views=2, seed=4, lo=0.02, hi=0.3)  # ragged: 70x45 is not tile aligned
+    dev, offs, flat = _staged(gpu, sc, D, tile_size)
+    bg = torch.rand(2, D, generator=torch.Generator().manual_seed(9)).to(gpu) if with_bg else None
+    out, alpha = rd.rasterize_to_pixels(dev["means2d"], dev["conics"], dev["colors"], dev["opacities"], sc.width,
+                                        sc.height, tile_size, offs, flat, backgrounds=bg)
+    _, out_r, alpha_r, amb = _oracle_raster(dev, offs, flat, sc, tile_size, bg, False)
+    assert alpha_r.max() > 0.9 and alpha_r.min() < 0.2
+    assert_image_close(out, out_r, amb, f"colors D={D} ts={tile_size}")
+    assert_image_close(alpha, alpha_r, amb, "alpha")
+
+
+@pytest.mark.parametrize("tile_size,D", [(16, 4), (16, 19), (16, 36), (16, 64), (16, 97), (8, 4), (8, 64)])
+@pytest.mark.parametrize("with_bg", [False, True])
+def test_raster_backward(gpu, tile_size, D, with_bg):
+    rd = _rendering()
+    sc = small_scene(n=600, w=70, h=45, views=2, seed=4, lo=0.02, hi=0.3)
+    dev, offs, flat = _staged(gpu, sc, D, tile_size)
+    bg = torch.rand(2, D, generator=torch.Generator().manual_seed(9)).to(gpu) if with_bg else None
+    cpu, out_r, alpha_r, amb = _oracle_raster(dev, offs, flat, sc, tile_size, bg, True)
+    g = torch.Generator().manual_seed(13)
+    vc = torch.randn(out_r.shape, generator=g)
+    va = torch.randn(alpha_r.shape, generator=g)
+    keep = (~amb)[..., None].float()  # a pixel that may legitimately flip a branch gets no cotangent
+    vc, va = vc * keep, va * keep
+    (out_r * vc.double()).sum().add((alpha_r * va.double()).sum()).backward()
+
+    leaves = {k: v.clone().requires_grad_(True) for k, v in dev.items()}
+    out, alpha = rd.rasterize_to_pixels(leaves["means2d"], leaves["conics"], leaves["colors"], leaves["opacities"],
+                                        sc.width, sc.height, tile_size, offs, flat, backgrounds=bg, absgrad=True)
+    ((out * vc.to(gpu)).sum() + (alpha * va.to(gpu)).sum()).backward()
+    for k in ("colors", "opacities", "conics", "means2d"):
+        assert_grad_close(leaves[k].grad, cpu[k].grad, f"{k} D={D} ts={tile_size}")
+    ab = leaves["means2d"].absgrad
+    assert ab.shape == leaves["means2d"].shape
+    assert (ab + 1e-6 * ab.abs().max() >= leaves["means2d"].grad.abs()).all()
+
+
+def test_raster_backward_colors_only(gpu):
+    """Geometry detached (the training-time feature pass, pogs/pogs.py:494-498): only colour gradients."""
+    rd = _rendering()
+    sc = small_scene(n=600, w=70, h=45, views=1, seed=6, lo=0.02, hi=0.3)
+    for D in (64, 96):
+        dev, offs, flat = _staged(gpu, sc, D, 16)
+        cpu, out_r, alpha_r, amb = _oracle_raster(dev, offs, flat, sc, 16, None, True)
+        vc = torch.randn(out_r.shape, generator=torch.Generator().manual_seed(1)) * (~amb)[..., None].float()
+        (out_r * vc.double()).sum().backward()
+        colors = dev["colors"].clone().requires_grad_(True)
+        out, _ = rd.rasterize_to_pixels(dev["means2d"], dev["conics"], colors, dev["opacities"], sc.width, sc.height,
+                                        16, offs, flat)
+        (out * vc.to(gpu)).sum().backward()
+        assert_grad_close(colors.grad, cpu["colors"].grad, f"colors-only D={D}")
+
+
+# ------------------------------------------------------------------------------------------------
+# the whole call
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode,tile_size,antialiased", [("RGB+ED", 16, False), ("RGB", 16, True), ("RGB+ED", 8, False)])
+def test_rasterization_end_to_end(gpu, mode, tile_size, antialiased):
+    rd = _rendering()
+    sc = small_scene(n=500, w=70, h=45, views=2, seed=8, lo=0.02, hi=0.3, f=6)
+    kw = dict(sh_degree=3, render_mode=mode, tile_size=tile_size, packed=False, absgrad=True,
+              rasterize_mode="antialiased" if antialiased else "classic")
+    a = scene_args(sc, device=gpu, requires_grad=True)
+    out, alpha, meta = rd.rasterization(**a, **kw)
+    meta["means2d"].retain_grad()
+    b = scene_args(sc, dtype=torch.float64, requires_grad=True)
+    out_r, alpha_r, meta_r = R.rasterization(**b, **kw, radii_override=meta["radii"].cpu())
+    amb = meta_r["ambiguous"]
+    assert torch.equal(meta["isect_ids"].cpu(), meta_r["isect_ids"]), "binning differs from the float64 oracle"
+    assert_image_close(out, out_r, amb, "render_colors")
+    assert_image_close(alpha, alpha_r, amb, "render_alphas")
+    assert set(meta.keys()) >= {"camera_ids", "gaussian_ids", "radii", "means2d", "depths", "conics", "opacities",
+                                "tile_width", "tile_height", "tiles_per_gauss", "isect_ids", "flatten_ids",
+                                "isect_offsets", "width", "height", "tile_size", "n_cameras"}
+    g = torch.Generator().manual_seed(21)
+    keep = (~amb)[..., None].float()
+    vc = torch.randn(out_r.shape, generator=g) * keep
+    va = torch.randn(alpha_r.shape, generator=g) * keep
+    ((out * vc.to(gpu)).sum() + (alpha * va.to(gpu)).sum()).backward()
+    (out_r * vc.double()).sum().add((alpha_r * va.double()).sum()).backward()
+    for k in ("means", "quats", "scales", "opacities", "colors", "features"):
+        assert_grad_close(a[k].grad, b[k].grad, k)
+    assert_grad_close(a["viewmats"].grad[:, :3, :], b["viewmats"].grad[:, :3, :], "viewmats")
+    assert meta["means2d"].grad is not None and meta["means2d"].absgrad is not None
+
+
+def test_rasterization_all_culled(gpu):
+    rd = _rendering()
+    sc = small_scene(n=64, seed=1)
+    sc.means[:, 2] -= 10.0  # everything behind the camera
+    a = scene_args(sc, device=gpu, requires_grad=True)
+    out, alpha, meta = rd.rasterization(**a, sh_degree=3, render_mode="RGB+ED", packed=False)
+    assert meta["isect_ids"].numel() == 0 and int(meta["radii"].sum()) == 0
+    assert out.abs().max().item() == 0 and alpha.abs().max().item() == 0
+    (out.sum() + alpha.sum()).backward()
+    assert a["means"].grad.abs().max().item() == 0
+
+
+def test_rasterization_rejects_bad_shapes(gpu):
+    rd = _rendering()
+    a = scene_args(small_scene(n=16), device=gpu)
+    with pytest.raises(AssertionError):
+        rd.rasterization(**{**a, "quats": a["quats"][:, :3]}, sh_degree=3)
+    with pytest.raises(AssertionError):
+        rd.rasterization(**a, sh_degree=4)
+    with pytest.raises(RuntimeError):
+        rd.rasterization(**scene_args(small_scene(n=16)), sh_degree=3)  # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size, size-independent properties (BASELINE configs' shapes)
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties(gpu):
+    """1M Gaussians at 1080p: (a) a constant-1 colour channel renders to alpha, (b) rendering is linear
+    in the colours, (c) the sorted keys are non-decreasing and offsets partition them."""
+    rd = _rendering()
+    from pogs_amd.scenes import make_scene
+
+    sc = make_scene(1_000_000, 1920, 1080, n_features=7, seed=0)
+    a = scene_args(sc, device=gpu)
+    f1 = a["features"]
+    f2 = torch.randn(f1.shape, generator=torch.Generator().manual_seed(3)).to(gpu)
+    ones = torch.ones(sc.n, 1, device=gpu)
+    geo = {k: a[k] for k in ("means", "quats", "scales", "opacities", "viewmats", "Ks", "width", "height")}
+    with torch.no_grad():
+        o1, al, meta = rd.rasterization(**geo, colors=torch.cat([f1, ones], 1), packed=False)
+        o2, _, _ = rd.rasterization(**geo, colors=torch.cat([f2, ones], 1), packed=False)
+        o3, _, _ = rd.rasterization(**geo, colors=torch.cat([2 * f1 - 3 * f2, ones], 1), packed=False)
+    assert (o1[..., -1:] - al).abs().max().item() <= 2e-5
+    lin = (2 * o1[..., :-1] - 3 * o2[..., :-1] - o3[..., :-1]).abs().max().item()
+    assert lin <= 1e-3, lin
+    ids = meta["isect_ids"]
+    assert ids.numel() > 1_000_000
+    assert bool((ids[1:] >= ids[:-1]).all())
+    offs = meta["isect_offsets"].flatten().long()
+    assert bool((offs[1:] >= offs[:-1]).all()) and int(offs[0]) == 0
+    tile_of = (ids >> 32)
+    probe = torch.randint(0, offs.numel(), (64,), generator=torch.Generator().manual_seed(0))
+    ends = torch.cat([offs[1:], torch.tensor([ids.numel()], device=gpu)])
+    for t in probe.tolist():
+        s, e = int(offs[t]), int(ends[t])
+        if e > s:
+            assert int(tile_of[s]) == t and int(tile_of[e - 1]) == t
+    assert int(meta["tiles_per_gauss"].sum()) == ids.numel()
