@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpix/s of one rasterization forward+backward at the POGS training-step shape
+(1M Gaussians, 1920x1080, SH-RGB + expected depth + 32 feature channels) on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one `rasterization()` call forward + backward (projection, SH, binning + sort, compositing and
+every backward kernel) on one camera per GPU with inputs resident in HBM; with N > 1 every rank renders a
+different view of the same (replicated) scene and the flat parameter-gradient buffer is mean-all-reduced
+over RCCL inside the step (weak scaling: per-GPU work fixed).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from pogs_amd import rendering  # noqa: E402
+from pogs_amd.dist import FlatGrads  # noqa: E402
+from pogs_amd.scenes import make_scene  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E nominal
+
+
+def stage_bytes(N, C, I, P, K, F, D, key_bits):
+    """Algorithmic bytes per entry point for one forward+backward call; they sum to
+    N(212+36K+8F) + I(108+24s+12D) + P(8D+20) with s = ceil(key_bits/8) radix passes."""
+    s = math.ceil(key_bits / 8)
+    cn = C * N
+    b = {
+        "pr_project_fwd": cn * (44 + 28),
+        "pr_sh_fwd": cn * (12 * K + 12),
+        "pr_isect_count": 0,
+        "pr_isect_emit_sort": I * (12 + 24 * s),
+        "pr_isect_offsets": I * 8,
+        "pr_raster_fwd": I * (28 + 4 * D) + P * (4 * D + 8),
+        "pr_raster_bwd": I * (28 + 4 * D) + I * (32 + 4 * D) + P * (4 * D + 12),
+        "pr_project_bwd": cn * (28 + 44 + 44),
+        "pr_sh_bwd": cn * (12 + 12 * K + 12 * K),
+    }
+    total = cn * (212 + 36 * K + 8 * F) + I * (108 + 24 * s + 12 * D) + P * (8 * D + 20)
+    b["other"] = total - sum(b.values())  # feature read/write + gradient hand-offs between entry points
+    return b, total
+
+
+def cpu_baseline(sc, F, tile_size, target_s=15.0):
+    """The oracle (a CPU port of the algorithm) timed on this host's cores on a bounded sample of the
+    same workload: full projection + SH + binning for all Gaussians, compositing forward+backward on an
+    evenly spread subset of tiles sized to ~target_s seconds."""
+    from oracle import gsplat_ref as R
+    from oracle import raster_c as RC
+
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    W, H = sc.width, sc.height
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        scales, opac = sc.log_scales.exp(), torch.sigmoid(sc.opacity_logits)
+        radii, means2d, depths, conics, _ = R.fully_fused_projection(sc.means, sc.quats, scales, sc.viewmats[:1],
+                                                                     sc.Ks[:1], W, H)
+        dirs = sc.means[None] - torch.inverse(sc.viewmats[:1])[:, None, :3, 3]
+        rgb = torch.clamp_min(R.spherical_harmonics(3, dirs, sc.sh[None], masks=radii > 0) + 0.5, 0.0)
+        cols = torch.cat([rgb, sc.features[None], depths[..., None]], dim=-1).contiguous()
+        tw, th = math.ceil(W / tile_size), math.ceil(H / tile_size)
+        _, ids, flat = R.isect_tiles(means2d, radii, depths, tile_size, tw, th)
+        offs = R.isect_offset_encode(ids, 1, tw, th)
+    t_front = time.perf_counter() - t0
+    D = cols.shape[-1]
+    opac = opac[None].contiguous()
+    g = torch.Generator().manual_seed(1)
+
+    def run(stride):
+        tiles = torch.arange(0, tw * th, stride, dtype=torch.int32)
+        t1 = time.perf_counter()
+        out, alpha, last = RC.raster_fwd(means2d, conics, cols, opac, W, H, tile_size, offs, flat, tiles=tiles)
+        vc = torch.randn(out.shape, generator=g)
+        va = torch.randn(alpha.shape, generator=g)
+        t2 = time.perf_counter()
+        RC.raster_bwd(means2d, conics, cols, opac, W, H, tile_size, offs, flat, alpha, last, vc, va, tiles=tiles)
+        t3 = time.perf_counter()
+        return tiles.numel(), (t2 - t1) - 0.0 + (t3 - t2)
+
+    n_probe, t_probe = run(64)
+    per_tile = max(t_probe / n_probe, 1e-6)
+    stride = max(1, int(math.ceil(tw * th * per_tile / target_s)))
+    n_tiles, t_rast = (n_probe, t_probe) if stride >= 64 else run(stride)
+    frac = n_tiles / float(tw * th)
+    pixels = frac * W * H
+    t_total = t_rast + t_front * frac
+    return {
+        "value": pixels / t_total / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
+        "sample": (f"1M-Gaussian 1080p scene: projection+SH+binning of all Gaussians in PyTorch CPU "
+                   f"({t_front:.1f} s, charged pro rata), C/OpenMP compositing fwd+bwd of every {stride}th tile "
+                   f"({n_tiles} of {tw * th} tiles, {t_rast:.1f} s), D={D}; projection/SH backward not included"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--features", type=int, default=32)
+    ap.add_argument("--tile-size", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-call", action="store_true",
+                    help="render RGB+ED and the features as two gsplat-signature calls instead of one fused call")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    N, W, H, F, ts = args.gaussians, args.width, args.height, args.features, args.tile_size
+    sc = make_scene(N, W, H, n_features=F, n_views=max(world, 1), seed=0)
+    view = rank % sc.viewmats.shape[0]
+    params = {
+        "means": sc.means, "quats": sc.quats, "log_scales": sc.log_scales, "opacity_logits": sc.opacity_logits,
+        "sh": sc.sh, "features": sc.features,
+    }
+    params = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in params.items()}
+    viewmat = sc.viewmats[view:view + 1].to(dev).contiguous()
+    K = sc.Ks[view:view + 1].to(dev).contiguous()
+    grads = FlatGrads(params.values())
+    D = 3 + F + 1
+    g = torch.Generator().manual_seed(100 + rank)
+    v_colors = torch.randn(1, H, W, D, generator=g).to(dev)
+    v_alpha = torch.randn(1, H, W, 1, generator=g).to(dev)
+    info = {}
+
+    def step():
+        grads.zero_()
+        scales = torch.exp(params["log_scales"])
+        opac = torch.sigmoid(params["opacity_logits"])
+        common = dict(means=params["means"], quats=params["quats"], scales=scales, opacities=opac, viewmats=viewmat,
+                      Ks=K, width=W, height=H, tile_size=ts, packed=False, near_plane=0.01, far_plane=1e10,
+                      sparse_grad=False, rasterize_mode="classic")
+        if args.two_call:
+            r1, a1, meta = rendering.rasterization(colors=params["sh"], sh_degree=3, render_mode="RGB+ED",
+                                                   absgrad=True, **common)
+            r2, a2, _ = rendering.rasterization(colors=params["features"], sh_degree=None, render_mode="RGB",
+                                                absgrad=False, **common)
+            torch.autograd.backward([r1, a1, r2, a2],
+                                    [v_colors[..., [0, 1, 2, D - 1]], v_alpha, v_colors[..., 3:D - 1], v_alpha])
+        else:
+            r, a, meta = rendering.rasterization(colors=params["sh"], sh_degree=3, render_mode="RGB+ED",
+                                                 absgrad=True, features=params["features"], **common)
+            torch.autograd.backward([r, a], [v_colors, v_alpha])
+        info["n_isects"] = meta["isect_ids"].numel()
+        info["tile_bits"] = (meta["tile_width"] * meta["tile_height"]).bit_length()
+        if world > 1:
+            grads.all_reduce_mean()
+
+    for _ in range(args.warmup):
+        step()
+    timer = rendering.StageTimer()
+    rendering.set_stage_timer(timer)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    rendering.set_stage_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        pixels = world * H * W
+        value = pixels / (elapsed / args.steps) / 1e6
+        I = info["n_isects"]
+        key_bits = 32 + info["tile_bits"]
+        per_stage, total_bytes = stage_bytes(N, 1, I, H * W, 16, F, D, key_bits)
+        summ = timer.summary()
+        stages = {k: v[1] / max(v[0], 1) * (v[0] / args.steps) for k, v in summ.items()}  # ms per step
+        dom = max(stages, key=stages.get)
+        launches, total_ms = summ[dom]
+        avg_ms = total_ms / launches
+        dom_bytes = per_stage[dom] / (launches / args.steps)
+        achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc))
+                if rec.get("workload") == f"{N}x{W}x{H}xF{F}ts{ts}":
+                    traffic = rec.get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpix/s fwd+bwd (1M Gauss, 1080p, RGB+32ch feat)", "value": value, "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": ("POGS training step shape: %d Gaussians, %dx%d, SH-RGB(deg 3)+ED+%d feature channels, "
+                             "fwd+bwd, absgrad, tile %d, 1 view per GPU%s" % (
+                                 N, W, H, F, ts, ", fused single call" if not args.two_call else ", two calls")),
+                "gaussians": N, "width": W, "height": H, "channels": D, "n_isects": I,
+                "parallelism": "camera-sharded dp%d, flat-gradient mean all-reduce (%.0f MB)" % (
+                    world, grads.nbytes() / 1e6) if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms,
+                "whole_call": {"algorithmic_bytes": total_bytes, "achieved": total_bytes / (ms_per_step * 1e-3) / 1e9,
+                               "frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            },
+            "stages_ms_per_step": {k: round(v, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, F, ts)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

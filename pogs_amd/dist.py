@@ -1,0 +1,83 @@
+"""Camera-sharded multi-GPU step: one process per GPU, one view per rank, Gaussian parameters replicated,
+parameter gradients mean-all-reduced over RCCL (xGMI).
+
+This is the reference's only parallelism -- DistributedDataParallel around a model that renders one random
+camera per rank (``src/pogs/dependencies/nerfstudio/nerfstudio/scripts/train.py:98,139-145``,
+``.../pipelines/base_pipeline.py:279-282``, ``pogs/pogs.py:263``) -- restated without DDP's bucket
+machinery: every parameter's ``.grad`` is a view into ONE flat float32 buffer, so the exchange step is a
+single large collective (few, large messages suit point-to-point xGMI links better than DDP's 25 MB
+buckets) and no gather/scatter copies are needed either side of it.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+class FlatGrads:
+    """Owns one flat gradient buffer; ``params[i].grad`` aliases a slice of it."""
+
+    def __init__(self, params: Iterable[Tensor]):
+        self.params: List[Tensor] = [p for p in params if p.requires_grad]
+        assert self.params, "no parameter requires grad"
+        dev, dt = self.params[0].device, self.params[0].dtype
+        total = 0
+        self.offsets = []
+        for p in self.params:
+            assert p.is_leaf and p.device == dev and p.dtype == dt
+            # keep every slice 256-byte aligned so kernels may use 16-byte accesses on it
+            total = (total + 63) // 64 * 64
+            self.offsets.append(total)
+            total += p.numel()
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+
+    def zero_(self) -> None:
+        """Zero all gradients in one fill; re-attaches the views if something replaced ``.grad``."""
+        self.flat.zero_()
+        for p, off in zip(self.params, self.offsets):
+            g = p.grad
+            if g is None or g.data_ptr() != self.flat.data_ptr() + off * self.flat.element_size():
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+
+    def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None, async_op: bool = False):
+        """DDP semantics: every rank ends with the mean over ranks of the per-view gradients."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return None
+        if dist.get_backend(group) == "gloo":  # gloo has no AVG
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+            if async_op:
+                return work
+            self.flat.div_(dist.get_world_size(group))
+            return None
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+
+def view_for_rank(n_views: int, rank: int, world: int) -> List[int]:
+    """Views of a batch handled by this rank: view v -> rank v mod world."""
+    return [v for v in range(n_views) if v % world == rank]
+
+
+def sharded_step(render_view, n_views: int, grads: FlatGrads, rank: int, world: int,
+                 group: Optional[dist.ProcessGroup] = None) -> Dict[str, float]:
+    """One multi-view step.  ``render_view(v)`` must run forward AND backward of view ``v`` (accumulating
+    into the parameters' ``.grad``).  Gradients of the views a rank owns are summed locally, divided by
+    the number of views so that the all-reduced SUM over ranks equals the mean over the batch."""
+    grads.zero_()
+    mine = view_for_rank(n_views, rank, world)
+    for v in mine:
+        render_view(v)
+    if world > 1:
+        # mean over the whole batch = (sum over ranks of local sums) / n_views
+        grads.flat.mul_(float(world) / float(n_views))
+        grads.all_reduce_mean(group)
+    elif n_views > 1:
+        grads.flat.div_(float(n_views))
+    return {"views": float(len(mine))}

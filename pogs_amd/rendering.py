@@ -30,6 +30,44 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class StageTimer:
+    """Optional per-entry-point device timing: HIP events recorded on the stream the kernels are launched
+    on (torch's current stream), read back after a synchronise.  Used by bench.py for the roofline line."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def record(self, name):
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.spans.setdefault(name, []).append(ev)
+        return ev
+
+    def summary(self):
+        """{name: (launches, total_ms)}; call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.spans.items()}
+
+
+_timer: Optional[StageTimer] = None
+
+
+def set_stage_timer(timer: Optional[StageTimer]) -> None:
+    global _timer
+    _timer = timer
+
+
+def _call(name: str, *args) -> None:
+    """Invoke one C-ABI entry point, raising RuntimeError on a non-zero status."""
+    fn = getattr(_lib.load(), name)
+    if _timer is None:
+        _lib.check(fn(*args), name)
+        return
+    a, b = _timer.record(name)
+    a.record()
+    rc = fn(*args)
+    b.record()
+    _lib.check(rc, name)
+
+
 def _rows(t: Tensor, width: int) -> Tuple[Tensor, int]:
     """Return (tensor, row stride in floats) for a [..., width] float32 tensor whose rows may be strided
     (e.g. a column slice of a packed buffer); copies only when the layout is not row-regular."""
@@ -77,10 +115,9 @@ class _Projection(torch.autograd.Function):
         conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
         comps = torch.empty(C, N, dtype=torch.float32, device=dev) if calc_compensations else None
         with torch.cuda.device(dev):
-            _lib.check(lib.pr_project_fwd(C, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(viewmats), _ptr(Ks),
+            _call("pr_project_fwd", C, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(viewmats), _ptr(Ks),
                                           width, height, eps2d, near_plane, far_plane, radius_clip, _ptr(radii),
-                                          _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(comps), _stream()),
-                       "pr_project_fwd")
+                                          _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(comps), _stream())
         ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii)
         ctx.args = (width, height, eps2d)
         ctx.mark_non_differentiable(radii)
@@ -106,10 +143,10 @@ class _Projection(torch.autograd.Function):
         v_scales = torch.empty(N, 3, dtype=torch.float32, device=dev)
         v_viewmats = torch.zeros(C, 4, 4, dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
         with torch.cuda.device(dev):
-            _lib.check(lib.pr_project_bwd(C, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(viewmats), _ptr(Ks),
+            _call("pr_project_bwd", C, N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(viewmats), _ptr(Ks),
                                           width, height, eps2d, _ptr(radii), _ptr(v_means2d), ld_m, _ptr(v_depths),
                                           _ptr(v_conics), ld_c, _ptr(v_comps), _ptr(v_means), _ptr(v_quats),
-                                          _ptr(v_scales), _ptr(v_viewmats), _stream()), "pr_project_bwd")
+                                          _ptr(v_scales), _ptr(v_viewmats), _stream())
         return (v_means if ctx.needs_input_grad[0] else None, v_quats if ctx.needs_input_grad[1] else None,
                 v_scales if ctx.needs_input_grad[2] else None, v_viewmats, None, None, None, None, None, None,
                 None, None)
@@ -126,8 +163,8 @@ class _SphericalHarmonics(torch.autograd.Function):
         means, campos, coeffs = means.contiguous(), campos.contiguous(), coeffs.contiguous()
         colors = torch.empty(C, N, 3, dtype=torch.float32, device=means.device)
         with torch.cuda.device(means.device):
-            _lib.check(lib.pr_sh_fwd(C, N, K, degree, _ptr(means), _ptr(campos), _ptr(coeffs), _ptr(radii),
-                                     int(post), _ptr(colors), 3, _stream()), "pr_sh_fwd")
+            _call("pr_sh_fwd", C, N, K, degree, _ptr(means), _ptr(campos), _ptr(coeffs), _ptr(radii),
+                                     int(post), _ptr(colors), 3, _stream())
         ctx.save_for_backward(means, campos, coeffs, radii)
         ctx.args = (degree, int(post))
         return colors
@@ -144,9 +181,8 @@ class _SphericalHarmonics(torch.autograd.Function):
         v_means = torch.empty(N, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         v_campos = torch.zeros(C, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
         with torch.cuda.device(dev):
-            _lib.check(lib.pr_sh_bwd(C, N, K, degree, _ptr(means), _ptr(campos), _ptr(coeffs), _ptr(radii), post,
-                                     _ptr(v_colors), ld, _ptr(v_coeffs), _ptr(v_means), _ptr(v_campos), _stream()),
-                       "pr_sh_bwd")
+            _call("pr_sh_bwd", C, N, K, degree, _ptr(means), _ptr(campos), _ptr(coeffs), _ptr(radii), post,
+                                     _ptr(v_colors), ld, _ptr(v_coeffs), _ptr(v_means), _ptr(v_campos), _stream())
         return None, v_means, v_campos, (v_coeffs if ctx.needs_input_grad[3] else None), None, None
 
 
@@ -166,18 +202,17 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     with torch.cuda.device(dev):
         nb = lib.pr_isect_count_scratch_bytes(C, N)
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-        _lib.check(lib.pr_isect_count(C, N, _ptr(means2d), _ptr(radii), tile_size, tile_width, tile_height,
-                                      _ptr(tiles_per_gauss), _ptr(cum), _ptr(scratch), nb, _stream()),
-                   "pr_isect_count")
+        _call("pr_isect_count", C, N, _ptr(means2d), _ptr(radii), tile_size, tile_width, tile_height,
+                                      _ptr(tiles_per_gauss), _ptr(cum), _ptr(scratch), nb, _stream())
         n_isects = int(cum[-1].item())  # the path's one device->host read
         isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
         flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
         if n_isects > 0:
             nb = lib.pr_isect_sort_scratch_bytes(C, N, n_isects)
             scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-            _lib.check(lib.pr_isect_emit_sort(C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(cum), tile_size,
+            _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(cum), tile_size,
                                               tile_width, tile_height, n_isects, _ptr(isect_ids), _ptr(flatten_ids),
-                                              _ptr(scratch), nb, _stream()), "pr_isect_emit_sort")
+                                              _ptr(scratch), nb, _stream())
     return tiles_per_gauss, isect_ids, flatten_ids
 
 
@@ -187,8 +222,8 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
     dev = isect_ids.device
     offsets = torch.empty(n_cameras, tile_height, tile_width, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.pr_isect_offsets(isect_ids.numel(), _ptr(isect_ids.contiguous()), n_cameras, tile_width,
-                                        tile_height, _ptr(offsets), _stream()), "pr_isect_offsets")
+        _call("pr_isect_offsets", isect_ids.numel(), _ptr(isect_ids.contiguous()), n_cameras, tile_width,
+                                        tile_height, _ptr(offsets), _stream())
     return offsets
 
 
@@ -209,10 +244,10 @@ class _Rasterize(torch.autograd.Function):
         render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.pr_raster_fwd(C, N, D, _ptr(means2d_c), _ptr(conics), _ptr(colors), _ptr(opacities),
+            _call("pr_raster_fwd", C, N, D, _ptr(means2d_c), _ptr(conics), _ptr(colors), _ptr(opacities),
                                          _ptr(backgrounds), width, height, tile_size, tw, th, _ptr(isect_offsets),
                                          _ptr(flatten_ids), flatten_ids.numel(), _ptr(render_colors),
-                                         _ptr(render_alphas), _ptr(last_ids), _stream()), "pr_raster_fwd")
+                                         _ptr(render_alphas), _ptr(last_ids), _stream())
         ctx.save_for_backward(means2d_c, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids,
                               render_alphas, last_ids)
         ctx.args = (width, height, tile_size, absgrad)
@@ -239,12 +274,12 @@ class _Rasterize(torch.autograd.Function):
         v_colors = torch.zeros(C, N, D, dtype=torch.float32, device=dev) if want_colors else None
         if geom or want_colors:
             with torch.cuda.device(dev):
-                _lib.check(lib.pr_raster_bwd(C, N, D, _ptr(means2d), _ptr(conics), _ptr(colors), _ptr(opacities),
+                _call("pr_raster_bwd", C, N, D, _ptr(means2d), _ptr(conics), _ptr(colors), _ptr(opacities),
                                              _ptr(backgrounds), width, height, tile_size, tw, th,
                                              _ptr(isect_offsets), _ptr(flatten_ids), flatten_ids.numel(),
                                              _ptr(render_alphas), _ptr(last_ids), _ptr(v_render_colors),
                                              _ptr(v_render_alphas), int(absgrad), int(geom), _ptr(v_geom),
-                                             _ptr(v_colors), _stream()), "pr_raster_bwd")
+                                             _ptr(v_colors), _stream())
         v_means2d = v_conics = v_opacities = None
         if geom:
             g = v_geom.view(C, N, 8)
