@@ -1,0 +1,81 @@
+"""The C-ABI library loads on a machine without a GPU and exports exactly what include/pogs_rast.h declares.
+No compute entry point is called here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pogs_rast.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = _declared()
+    for must in ("pr_project_fwd", "pr_project_bwd", "pr_sh_fwd", "pr_sh_bwd", "pr_isect_count",
+                 "pr_isect_emit_sort", "pr_isect_offsets", "pr_raster_fwd", "pr_raster_bwd", "pr_version"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from pogs_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "build with `make -C pogs_amd/csrc` (or __graft_entry__.build())"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in pogs_rast.h but not exported"
+
+
+def test_python_binding_covers_the_header():
+    from pogs_amd import _lib
+
+    assert sorted(_lib.SIGNATURES.keys()) == _declared()
+    lib = _lib.load()
+    assert lib.pr_version() >> 16 == 1
+    assert lib.pr_error_string(0) == b"ok"
+    assert b"invalid" in lib.pr_error_string(-1)
+    assert lib.pr_max_channels() >= 97  # widest render in the reference: 96 hash features (+1 depth)
+
+
+def test_argument_validation_needs_no_gpu():
+    """Entry points reject malformed arguments before touching the device."""
+    from pogs_amd import _lib
+
+    lib = _lib.load()
+    assert lib.pr_project_fwd(1, 4, None, None, None, None, None, 0, 10, 0.3, 0.01, 1e10, 0.0,
+                              None, None, None, None, None, None) == -1          # width 0
+    assert lib.pr_project_fwd(1, 4, None, None, None, None, None, 8, 8, 0.3, 0.01, 1e10, 0.0,
+                              None, None, None, None, None, None) == -1          # null pointers
+    assert lib.pr_sh_fwd(1, 4, 16, 4, None, None, None, None, 1, None, 3, None) == -2   # degree 4 unsupported
+    assert lib.pr_raster_fwd(1, 4, 3, None, None, None, None, None, 64, 64, 12, 6, 6, None, None, 0,
+                             None, None, None, None) == -2                        # tile size 12 unsupported
+    assert lib.pr_raster_fwd(1, 4, 3, None, None, None, None, None, 64, 64, 16, 2, 2, None, None, 0,
+                             None, None, None, None) == -1                        # tile grid does not cover the image
+
+
+def test_rasterization_fails_loudly_without_gpu_tensors():
+    import torch
+
+    from pogs_amd import rendering
+    from tests._util import scene_args, small_scene
+
+    a = scene_args(small_scene(n=8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rendering.rasterization(**a, sh_degree=3)
+    del torch
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pogs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "oracle/" not in text, f
