@@ -50,6 +50,43 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
   return v;
 }
 
+// Sum over the 16 lanes of each DPP row; the row total is valid in the row's last lane (15, 31, 47, 63).
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+  v = dpp_add<0x111>(v);
+  v = dpp_add<0x112>(v);
+  v = dpp_add<0x114>(v);
+  v = dpp_add<0x118>(v);
+  return v;
+}
+
+// "Transposed" pair reductions built on gfx950's lane-swap instructions: two values go in, ONE register
+// comes out in which half of the lanes carry a partial sum of `a` and the other half one of `b` -- the
+// number of live values halves at every level instead of every lane carrying every sum.
+//   swap32_add: lanes 0..31 <- a[l] + a[l+32];   lanes 32..63 <- b[l-32] + b[l]
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false,
+                                            false);
+  unsigned r0 = r[0], r1 = r[1];
+  // Keep the two results as distinct values: without this barrier hipcc (ROCm 7.2) folds the float add of
+  // the intrinsic's two results into r0 + r0.
+  asm volatile("" : "+v"(r0), "+v"(r1));
+  return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+//   swap16_add: rows 0,2 <- a.row(r) + a.row(r+1);   rows 1,3 <- b.row(r-1) + b.row(r)
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false,
+                                            false);
+  unsigned r0 = r[0], r1 = r[1];
+  asm volatile("" : "+v"(r0), "+v"(r1));
+  return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+
+// Reduce four per-lane values over the wavefront.  On return, the LAST lane of DPP row r (lane 16r+15)
+// holds the wave total of v[kQuadSlot[r]], i.e. rows 0..3 carry values 0, 2, 1, 3.
+__device__ __forceinline__ float quad_reduce(float v0, float v1, float v2, float v3) {
+  return row_sum_to_lane15(swap16_add(swap32_add(v0, v1), swap32_add(v2, v3)));
+}
+
 __device__ __forceinline__ float wave_sum_all(float v) {
   v = wave_sum_to_lane63(v);
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));

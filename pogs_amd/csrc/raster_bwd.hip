@@ -9,6 +9,11 @@
 //   v_colour_g += fac * v_out_pixel
 // Keeping the scalar B instead of a per-channel "colour behind" buffer halves the per-pair channel
 // work and removes D registers per pixel.
+//
+// Reduction over the wavefront's pixels: values are produced four at a time and folded immediately by
+// the lane-swap "transposed" reduction (quad_reduce in common.h), so only one register per four values
+// stays live; the last lane of each DPP row then owns the totals of a quarter of the values, drops them
+// into the wave's LDS slice, and one lane per value issues the atomics (contiguous per Gaussian).
 #include "raster_common.h"
 
 namespace pr {
@@ -25,6 +30,8 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
   using Rg = Region<TS, PPL>;
   constexpr int ROW = color_row(CD);
   constexpr int CDP = round4(CD);
+  constexpr int NQ = CDP / 4;                 // colour quads
+  constexpr int NV = CDP + (GEOM ? 8 : 0);    // values reduced per Gaussian
   __shared__ WaveLds<CD> lds[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -41,7 +48,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
   const int range_lo = isect_offsets[tile_flat];
   const int nch = min(CD, D - ch_off);
 
-  float T[PPL], Bsum[PPL], W[PPL], vout[PPL][CD];
+  float T[PPL], Bsum[PPL], W[PPL], vout[PPL][CDP];
   int last[PPL];
   const float px0 = (float)x0 + 0.5f, py0 = (float)y0 + 0.5f;
   int max_last = range_lo;
@@ -55,14 +62,14 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     W[j] = 0.f;
     last[j] = range_lo;
 #pragma unroll
-    for (int k = 0; k < CD; ++k) vout[j][k] = 0.f;
+    for (int k = 0; k < CDP; ++k) vout[j][k] = 0.f;
     if (inside) {
       T[j] = 1.f - render_alphas[pix];
       last[j] = last_ids[pix];
       const float *src = v_render_colors + pix * D + ch_off;
       if (((D | ch_off) & 3) == 0) {
 #pragma unroll
-        for (int k = 0; k + 3 < CD; k += 4)
+        for (int k = 0; k + 3 < CDP; k += 4)
           if (k < nch) {
             const float4 v = *reinterpret_cast<const float4 *>(src + k);
             vout[j][k] = v.x; vout[j][k + 1] = v.y; vout[j][k + 2] = v.z; vout[j][k + 3] = v.w;
@@ -88,11 +95,29 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) max_last = max(max_last, __shfl_xor(max_last, m));
 
+  // Which reduced value this lane hands to the atomics, and where it goes (set per Gaussian below).
+  // Row r's last lane ends up with value 4*q + slot(r) of quad q, slot = {0,2,1,3}.
+  const int row = lane >> 4;
+  const int slot = ((row & 1) << 1) | (row >> 1);
+  const bool row_tail = (lane & 15) == 15;
+  // post-scale of the geometry totals: x y (-ln2), conic a c (1/2), b, opacity (1), |x| |y| (ln2)
+  float gscale = 1.f;
+  if (GEOM) {
+    const int gi = lane - CDP;
+    gscale = (gi == 0 || gi == 1) ? -LN2 : (gi == 2 || gi == 4) ? 0.5f : (gi == 6 || gi == 7) ? LN2 : 1.f;
+  }
+
+  const float rx0 = (float)(tx * TS) + 0.5f, ry0 = (float)(ty * TS + sub * Rg::RH) + 0.5f;
+  const float rx1 = (float)min(tx * TS + TS, width) - 0.5f;
+  const float ry1 = (float)min(ty * TS + sub * Rg::RH + Rg::RH, height) - 0.5f;
   for (int bend = max_last; bend > range_lo; bend -= WAVE) {
     const int first = max(range_lo, bend - WAVE);
     const int count = bend - first;
-    stage_batch<CD>(L, lane, first, count, flatten_ids, means2d, conics, opacities, colors, D, ch_off);
-    for (int t = count - 1; t >= 0; --t) {
+    unsigned long long todo = stage_batch<CD>(L, lane, first, count, flatten_ids, means2d, conics, opacities,
+                                              colors, D, ch_off, rx0, ry0, rx1, ry1);
+    while (todo) {
+      const int t = 63 - __builtin_clzll(todo);
+      todo &= ~(1ull << t);
       const int idx = first + t;
       const float4 g = L.g4[t];
       const float2 h = L.g2[t];
@@ -128,31 +153,34 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         T[j] = active[j] ? T[j] * ra[j] : T[j];
         fac[j] = active[j] ? alpha[j] * T[j] : 0.f;
       }
-      float S[PPL], vc[CD];
+      float S[PPL];
 #pragma unroll
       for (int j = 0; j < PPL; ++j) S[j] = 0.f;
       const float4 *crow = reinterpret_cast<const float4 *>(L.col + t * ROW);
+      const int gid = L.ids[t];
+      float *red = L.red;
 #pragma unroll
-      for (int q = 0; q < CDP / 4; ++q) {
+      for (int q = 0; q < NQ; ++q) {
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (GEOM) c4 = crow[q];
         const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+        float vc[4];
 #pragma unroll
         for (int ei = 0; ei < 4; ++ei) {
           const int k = 4 * q + ei;
-          if (k < CD) {
-            float a = 0.f;
+          float a = 0.f;
 #pragma unroll
-            for (int j = 0; j < PPL; ++j) {
-              if (GEOM) S[j] = fmaf(cv[ei], vout[j][k], S[j]);
-              a = fmaf(fac[j], vout[j][k], a);
-            }
-            vc[k] = a;
+          for (int j = 0; j < PPL; ++j) {
+            if (GEOM) S[j] = fmaf(cv[ei], vout[j][k], S[j]);
+            a = fmaf(fac[j], vout[j][k], a);
           }
+          vc[ei] = a;
         }
+        const float tot = quad_reduce(vc[0], vc[1], vc[2], vc[3]);
+        if (row_tail) red[4 * q + slot] = tot;
       }
-      float geo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // x y a b c o |x| |y|
       if (GEOM) {
+        float geo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // x y a b c o |x| |y|
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
           const int jx = j % Rg::BW, jy = j / Rg::BW;
@@ -174,41 +202,30 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
           geo[6] += fabsf(vx);
           geo[7] += fabsf(vy);
         }
-      }
-      // wave totals -> lane 63 -> LDS -> one lane per value -> atomics
-#pragma unroll
-      for (int k = 0; k < CD; ++k) vc[k] = wave_sum_to_lane63(vc[k]);
-      if (GEOM) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) geo[k] = wave_sum_to_lane63(geo[k]);
-      }
-      if (lane == 63) {
-#pragma unroll
-        for (int k = 0; k + 3 < CDP; k += 4) {
-          float4 v;
-          v.x = vc[k];
-          v.y = (k + 1 < CD) ? vc[k + 1] : 0.f;
-          v.z = (k + 2 < CD) ? vc[k + 2] : 0.f;
-          v.w = (k + 3 < CD) ? vc[k + 3] : 0.f;
-          *reinterpret_cast<float4 *>(L.red + k) = v;
-        }
-        if (GEOM) {
-          *reinterpret_cast<float4 *>(L.red + CDP) =
-              make_float4(-LN2 * geo[0], -LN2 * geo[1], 0.5f * geo[2], geo[3]);
-          *reinterpret_cast<float4 *>(L.red + CDP + 4) = make_float4(0.5f * geo[4], geo[5], LN2 * geo[6], LN2 * geo[7]);
+        const float t0 = quad_reduce(geo[0], geo[1], geo[2], geo[3]);
+        const float t1 = quad_reduce(geo[4], geo[5], geo[6], geo[7]);
+        if (row_tail) {
+          red[CDP + slot] = t0;
+          red[CDP + 4 + slot] = t1;
         }
       }
-      const int gid = L.ids[t];
-      if (v_colors) {
+      // one lane per value: colours go to v_colors[gid, ch_off + k], the 8 geometry values to v_geom[gid, :]
 #pragma unroll
-        for (int k0 = 0; k0 < CD; k0 += WAVE) {
-          const int k = k0 + lane;
-          if (k < nch) atomicAdd(v_colors + (int64_t)gid * D + ch_off + k, L.red[k]);
+      for (int k0 = 0; k0 < NV; k0 += WAVE) {
+        const int k = k0 + lane;
+        if (k < NV) {
+          const float v = red[k];
+          if (k < CDP) {
+            if (v_colors && k < nch) atomicAdd(v_colors + (int64_t)gid * D + ch_off + k, v);
+          } else if (GEOM) {
+            const int gi = k - CDP;
+            const float sc = (k0 == 0) ? gscale
+                                       : ((gi == 0 || gi == 1) ? -LN2
+                                          : (gi == 2 || gi == 4) ? 0.5f
+                                          : (gi == 6 || gi == 7) ? LN2 : 1.f);
+            if (gi < (absgrad ? 8 : 6)) atomicAdd(v_geom + (int64_t)gid * 8 + gi, v * sc);
+          }
         }
-      }
-      if (GEOM) {
-        const int ng = absgrad ? 8 : 6;
-        if (lane < ng) atomicAdd(v_geom + (int64_t)gid * 8 + lane, L.red[CDP + lane]);
       }
     }
   }

@@ -59,44 +59,75 @@ struct alignas(16) WaveLds {
   float red[round4(CD) + 16];   // backward: per-Gaussian totals on their way to the atomics
 };
 
+// Exact footprint test of one Gaussian against a pixel-centre rectangle [rx0,rx1] x [ry0,ry1]: the
+// minimum of the (convex) quadratic form sigma over the rectangle bounds the largest alpha any pixel of
+// the region can see.  If even that is below 1/255 the Gaussian cannot contribute to this region (the
+// square 3-sigma bounding box that built the tile lists is far looser for elongated or faint Gaussians).
+// Conservative by a margin of 1e-3 in the exponent; non-positive-definite conics are always kept.
+__device__ __forceinline__ bool touches_region(float gx, float gy, float o, float a, float b, float c, float rx0,
+                                               float ry0, float rx1, float ry1) {
+  if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return true;
+  const float xl = rx0 - gx, xr = rx1 - gx, yl = ry0 - gy, yr = ry1 - gy;
+  const float X = fminf(fmaxf(0.f, xl), xr), Y = fminf(fmaxf(0.f, yl), yr);  // nearest rectangle point per axis
+  float smin = 0.f;
+  if (X != 0.f || Y != 0.f) {
+    float s1 = 3.0e38f, s2 = 3.0e38f;
+    if (X != 0.f) {
+      const float uy = fminf(fmaxf(-b * X / c, yl), yr);
+      s1 = 0.5f * (a * X * X + c * uy * uy) + b * X * uy;
+    }
+    if (Y != 0.f) {
+      const float ux = fminf(fmaxf(-b * Y / a, xl), xr);
+      s2 = 0.5f * (a * ux * ux + c * Y * Y) + b * ux * Y;
+    }
+    smin = fmaxf(fminf(s1, s2), 0.f);
+  }
+  return o * __builtin_amdgcn_exp2f(1e-3f - smin * LOG2E) >= ALPHA_MIN;
+}
+
 // Stage up to 64 intersections [first, first+count) of the sorted list: lane j loads Gaussian j.
+// Returns the wave-wide mask of staged Gaussians whose footprint reaches the region.
 template <int CD>
-__device__ __forceinline__ void stage_batch(WaveLds<CD> &L, int lane, int first, int count,
-                                            const int32_t *__restrict__ flatten_ids,
-                                            const float *__restrict__ means2d, const float *__restrict__ conics,
-                                            const float *__restrict__ opacities, const float *__restrict__ colors,
-                                            int D, int ch_off) {
+__device__ __forceinline__ unsigned long long stage_batch(
+    WaveLds<CD> &L, int lane, int first, int count, const int32_t *__restrict__ flatten_ids,
+    const float *__restrict__ means2d, const float *__restrict__ conics, const float *__restrict__ opacities,
+    const float *__restrict__ colors, int D, int ch_off, float rx0, float ry0, float rx1, float ry1) {
   constexpr int ROW = color_row(CD);
+  bool keep = false;
   if (lane < count) {
     int g = flatten_ids[first + lane];
     float2 xy = *reinterpret_cast<const float2 *>(means2d + 2 * (int64_t)g);
     float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
     float o = opacities[g];
-    L.g4[lane] = make_float4(xy.x, xy.y, o, -0.5f * LOG2E * ca);
-    L.g2[lane] = make_float2(-LOG2E * cb, -0.5f * LOG2E * cc);
-    L.ids[lane] = g;
-    const float *src = colors + (int64_t)g * D + ch_off;
-    int nch = D - ch_off;  // channels available from ch_off on
-    float *dst = L.col + lane * ROW;
-    if (((D | ch_off) & 3) == 0) {
+    keep = touches_region(xy.x, xy.y, o, ca, cb, cc, rx0, ry0, rx1, ry1);
+    if (keep) {
+      L.g4[lane] = make_float4(xy.x, xy.y, o, -0.5f * LOG2E * ca);
+      L.g2[lane] = make_float2(-LOG2E * cb, -0.5f * LOG2E * cc);
+      L.ids[lane] = g;
+      const float *src = colors + (int64_t)g * D + ch_off;
+      int nch = D - ch_off;  // channels available from ch_off on
+      float *dst = L.col + lane * ROW;
+      if (((D | ch_off) & 3) == 0) {
 #pragma unroll
-      for (int k = 0; k < round4(CD); k += 4) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < nch) v = *reinterpret_cast<const float4 *>(src + k);
-        *reinterpret_cast<float4 *>(dst + k) = v;
-      }
-    } else {
+        for (int k = 0; k < round4(CD); k += 4) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (k < nch) v = *reinterpret_cast<const float4 *>(src + k);
+          *reinterpret_cast<float4 *>(dst + k) = v;
+        }
+      } else {
 #pragma unroll
-      for (int k = 0; k < round4(CD); k += 4) {
-        float4 v;
-        v.x = (k + 0 < nch) ? src[k + 0] : 0.f;
-        v.y = (k + 1 < nch) ? src[k + 1] : 0.f;
-        v.z = (k + 2 < nch) ? src[k + 2] : 0.f;
-        v.w = (k + 3 < nch) ? src[k + 3] : 0.f;
-        *reinterpret_cast<float4 *>(dst + k) = v;
+        for (int k = 0; k < round4(CD); k += 4) {
+          float4 v;
+          v.x = (k + 0 < nch) ? src[k + 0] : 0.f;
+          v.y = (k + 1 < nch) ? src[k + 1] : 0.f;
+          v.z = (k + 2 < nch) ? src[k + 2] : 0.f;
+          v.w = (k + 3 < nch) ? src[k + 3] : 0.f;
+          *reinterpret_cast<float4 *>(dst + k) = v;
+        }
       }
     }
   }
+  return __builtin_amdgcn_ballot_w64(keep);
 }
 
 }  // namespace pr

@@ -44,11 +44,18 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     for (int k = 0; k < CD; ++k) acc[j][k] = 0.f;
   }
 
+  // pixel-centre rectangle of this wave's region, clipped to the image
+  const float rx0 = (float)(tx * TS) + 0.5f, ry0 = (float)(ty * TS + sub * Rg::RH) + 0.5f;
+  const float rx1 = (float)min(tx * TS + TS, width) - 0.5f;
+  const float ry1 = (float)min(ty * TS + sub * Rg::RH + Rg::RH, height) - 0.5f;
   bool all_done = false;
   for (int first = range_lo; first < range_hi && !all_done; first += WAVE) {
     const int count = min(WAVE, range_hi - first);
-    stage_batch<CD>(L, lane, first, count, flatten_ids, means2d, conics, opacities, colors, D, ch_off);
-    for (int t = 0; t < count; ++t) {
+    unsigned long long todo = stage_batch<CD>(L, lane, first, count, flatten_ids, means2d, conics, opacities,
+                                              colors, D, ch_off, rx0, ry0, rx1, ry1);
+    while (todo) {
+      const int t = __builtin_ctzll(todo);
+      todo &= todo - 1;
       const float4 g = L.g4[t];
       const float2 h = L.g2[t];
       float vis[PPL];
