@@ -69,7 +69,7 @@ __device__ __forceinline__ float swap32_add(float a, float b) {
   unsigned r0 = r[0], r1 = r[1];
   // Keep the two results as distinct values: without this barrier hipcc (ROCm 7.2) folds the float add of
   // the intrinsic's two results into r0 + r0.
-  asm volatile("" : "+v"(r0), "+v"(r1));
+  asm("" : "+v"(r0), "+v"(r1));
   return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
 }
 //   swap16_add: rows 0,2 <- a.row(r) + a.row(r+1);   rows 1,3 <- b.row(r-1) + b.row(r)
@@ -77,14 +77,21 @@ __device__ __forceinline__ float swap16_add(float a, float b) {
   auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false,
                                             false);
   unsigned r0 = r[0], r1 = r[1];
-  asm volatile("" : "+v"(r0), "+v"(r1));
+  asm("" : "+v"(r0), "+v"(r1));
   return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
 }
 
-// Reduce four per-lane values over the wavefront.  On return, the LAST lane of DPP row r (lane 16r+15)
-// holds the wave total of v[kQuadSlot[r]], i.e. rows 0..3 carry values 0, 2, 1, 3.
+// Fold four per-lane values across the four DPP rows.  On return every lane of row r holds the sum over
+// the 4 lanes {c, c+16, c+32, c+48} (c = its column) of value slot(r), slot = {0, 2, 1, 3}; what is left
+// is the sum over the 16 columns of a row.
+__device__ __forceinline__ float quad_fold_rows(float v0, float v1, float v2, float v3) {
+  return swap16_add(swap32_add(v0, v1), swap32_add(v2, v3));
+}
+
+// Full reduction of four values: the LAST lane of DPP row r (lane 16r+15) holds the wave total of
+// value slot(r).
 __device__ __forceinline__ float quad_reduce(float v0, float v1, float v2, float v3) {
-  return row_sum_to_lane15(swap16_add(swap32_add(v0, v1), swap32_add(v2, v3)));
+  return row_sum_to_lane15(quad_fold_rows(v0, v1, v2, v3));
 }
 
 __device__ __forceinline__ float wave_sum_all(float v) {

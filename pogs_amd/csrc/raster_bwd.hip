@@ -10,10 +10,11 @@
 // Keeping the scalar B instead of a per-channel "colour behind" buffer halves the per-pair channel
 // work and removes D registers per pixel.
 //
-// Reduction over the wavefront's pixels: values are produced four at a time and folded immediately by
-// the lane-swap "transposed" reduction (quad_reduce in common.h), so only one register per four values
-// stays live; the last lane of each DPP row then owns the totals of a quarter of the values, drops them
-// into the wave's LDS slice, and one lane per value issues the atomics (contiguous per Gaussian).
+// Reduction over the wavefront's pixels: values are produced four at a time and folded across the four
+// DPP rows by the lane-swap "transposed" reduction (quad_fold_rows in common.h): one register per four
+// values, every lane of row r holding a 4-lane partial of value 4q+slot(r).  Each quad's register goes to
+// the wave's LDS slice as one unpredicated store; lane v then reads back the 16 partials of value v as
+// four 16-byte loads, adds them, and issues the atomic -- contiguous addresses per Gaussian.
 #include "raster_common.h"
 
 namespace pr {
@@ -97,9 +98,9 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 
   // Which reduced value this lane hands to the atomics, and where it goes (set per Gaussian below).
   // Row r's last lane ends up with value 4*q + slot(r) of quad q, slot = {0,2,1,3}.
-  const int row = lane >> 4;
-  const int slot = ((row & 1) << 1) | (row >> 1);
-  const bool row_tail = (lane & 15) == 15;
+  // lane v < NV owns value v = 4*q + s: its 16 partials sit in row r(s) of quad q's 64-float line
+  const int own_q = lane >> 2, own_row = ((lane & 1) << 1) | ((lane >> 1) & 1);  // slot s -> row {0,2,1,3}
+  const float4 *own = reinterpret_cast<const float4 *>(L.red + own_q * 68 + own_row * 16);
   // post-scale of the geometry totals: x y (-ln2), conic a c (1/2), b, opacity (1), |x| |y| (ln2)
   float gscale = 1.f;
   if (GEOM) {
@@ -176,8 +177,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
           }
           vc[ei] = a;
         }
-        const float tot = quad_reduce(vc[0], vc[1], vc[2], vc[3]);
-        if (row_tail) red[4 * q + slot] = tot;
+        red[q * 68 + lane] = quad_fold_rows(vc[0], vc[1], vc[2], vc[3]);
       }
       if (GEOM) {
         float geo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // x y a b c o |x| |y|
@@ -202,19 +202,18 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
           geo[6] += fabsf(vx);
           geo[7] += fabsf(vy);
         }
-        const float t0 = quad_reduce(geo[0], geo[1], geo[2], geo[3]);
-        const float t1 = quad_reduce(geo[4], geo[5], geo[6], geo[7]);
-        if (row_tail) {
-          red[CDP + slot] = t0;
-          red[CDP + 4 + slot] = t1;
-        }
+        red[NQ * 68 + lane] = quad_fold_rows(geo[0], geo[1], geo[2], geo[3]);
+        red[(NQ + 1) * 68 + lane] = quad_fold_rows(geo[4], geo[5], geo[6], geo[7]);
       }
       // one lane per value: colours go to v_colors[gid, ch_off + k], the 8 geometry values to v_geom[gid, :]
 #pragma unroll
       for (int k0 = 0; k0 < NV; k0 += WAVE) {
         const int k = k0 + lane;
         if (k < NV) {
-          const float v = red[k];
+          const float4 *src = own + k0 / 4 * 17;  // 64 values further = 16 quads = 16*68 floats
+          const float4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+          const float v = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w)) +
+                          (((p2.x + p2.y) + (p2.z + p2.w)) + ((p3.x + p3.y) + (p3.z + p3.w)));
           if (k < CDP) {
             if (v_colors && k < nch) atomicAdd(v_colors + (int64_t)gid * D + ch_off + k, v);
           } else if (GEOM) {
@@ -246,7 +245,7 @@ static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, con
   return check_launch("raster_bwd_kernel");
 }
 
-static const int kChunks[] = {4, 8, 16, 24, 32, 36, 48, 64, 100, 128};
+static const int kChunks[] = {4, 8, 16, 24, 32, 36, 48, 64, 100};
 static int pick_chunk(int want) {
   for (int c : kChunks)
     if (c >= want) return c;
@@ -257,7 +256,7 @@ static int pick_chunk(int want) {
 
 using namespace pr;
 
-extern "C" int pr_max_channels(void) { return 128; }
+extern "C" int pr_max_channels(void) { return 100; }
 
 #define BWD_ARGS                                                                                                     \
   C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,       \
@@ -300,12 +299,12 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
     if (tile_size == 16) {
       switch (cd) {
         BWD_CASE(16, 4, 4) BWD_CASE(16, 4, 8) BWD_CASE(16, 4, 16) BWD_CASE(16, 4, 24) BWD_CASE(16, 4, 32)
-        BWD_CASE(16, 4, 36) BWD_CASE(16, 2, 48) BWD_CASE(16, 2, 64) BWD_CASE(16, 1, 100) BWD_CASE(16, 1, 128)
+        BWD_CASE(16, 4, 36) BWD_CASE(16, 2, 48) BWD_CASE(16, 2, 64) BWD_CASE(16, 1, 100)
       }
     } else {
       switch (cd) {
         BWD_CASE(8, 1, 4) BWD_CASE(8, 1, 8) BWD_CASE(8, 1, 16) BWD_CASE(8, 1, 24) BWD_CASE(8, 1, 32)
-        BWD_CASE(8, 1, 36) BWD_CASE(8, 1, 48) BWD_CASE(8, 1, 64) BWD_CASE(8, 1, 100) BWD_CASE(8, 1, 128)
+        BWD_CASE(8, 1, 36) BWD_CASE(8, 1, 48) BWD_CASE(8, 1, 64) BWD_CASE(8, 1, 100)
       }
     }
     if (rc) return rc;

@@ -56,7 +56,9 @@ struct alignas(16) WaveLds {
   float2 g2[WAVE];              // B' (= -b log2e), C' (= -0.5 c log2e)
   int32_t ids[WAVE];            // flat Gaussian index
   float col[WAVE * color_row(CD)];
-  float red[round4(CD) + 16];   // backward: per-Gaussian totals on their way to the atomics
+  // backward: row-folded partial sums of the per-Gaussian values, [quad][lane] with a 68-float pitch so
+  // that the 16-float row segments read back by consecutive lanes fall on distinct banks
+  float red[(round4(CD) / 4 + 2) * 68];
 };
 
 // Exact footprint test of one Gaussian against a pixel-centre rectangle [rx0,rx1] x [ry0,ry1]: the
