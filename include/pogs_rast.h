@@ -99,14 +99,18 @@ int pr_isect_offsets(int64_t n_isects, const int64_t *isect_ids, int C, int tile
 
 /* ---- compositing: stands in for gsplat `rasterize_to_pixels` forward/backward --------------------------
  * means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] backgrounds[C,D] (may be NULL).
+ * ed_channel >= 0 names the channel that holds depth and is to be output as EXPECTED depth, i.e. divided by
+ * max(alpha, 1e-10) (what gsplat's `rasterization` does after the kernel for render modes ED / RGB+ED);
+ * -1 = none.
  * Out: render_colors[C,H,W,D], render_alphas[C,H,W], last_ids[C,H,W] int32 (one past the index of the
  * last intersection that contributed to the pixel; the tile's first index when none did). */
 int pr_raster_fwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
                   const float *opacities, const float *backgrounds, int width, int height, int tile_size,
                   int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
-                  int64_t n_isects, float *render_colors, float *render_alphas, int32_t *last_ids,
-                  void *stream);
-/* v_render_colors[C,H,W,D], v_render_alphas[C,H,W].
+                  int64_t n_isects, int ed_channel, float *render_colors, float *render_alphas,
+                  int32_t *last_ids, void *stream);
+/* v_render_colors[C,H,W,D], v_render_alphas[C,H,W]; render_colors (the forward output) is read only when
+ * ed_channel >= 0 and may be NULL otherwise.
  * Out, all zero-filled by the caller and accumulated into with float atomics:
  *   v_geom[C*N,8] = (v_means2d.x, v_means2d.y, v_conic.a, v_conic.b, v_conic.c, v_opacity,
  *                    |v_means2d|.x, |v_means2d|.y)  -- the last two only when absgrad != 0;
@@ -116,8 +120,9 @@ int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics
                   const float *opacities, const float *backgrounds, int width, int height, int tile_size,
                   int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
                   int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
-                  const float *v_render_colors, const float *v_render_alphas, int absgrad, int geom_grad,
-                  float *v_geom, float *v_colors, void *stream);
+                  const float *render_colors, int ed_channel, const float *v_render_colors,
+                  const float *v_render_alphas, int absgrad, int geom_grad, float *v_geom, float *v_colors,
+                  void *stream);
 
 #ifdef __cplusplus
 }

@@ -34,9 +34,9 @@ SIGNATURES = {
                                    _P]),
     "pr_isect_offsets": (c_int, [c_int64, _P, c_int, c_int, c_int, _P, _P]),
     "pr_raster_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P,
-                              c_int64, _P, _P, _P, _P]),
+                              c_int64, c_int, _P, _P, _P, _P]),
     "pr_raster_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P,
-                              c_int64, _P, _P, _P, _P, c_int, c_int, _P, _P, _P]),
+                              c_int64, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P]),
 }
 
 _lib = None

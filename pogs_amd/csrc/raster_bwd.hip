@@ -25,9 +25,9 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
     const int32_t *__restrict__ flatten_ids, int n_isects, const float *__restrict__ render_alphas,
-    const int32_t *__restrict__ last_ids, const float *__restrict__ v_render_colors,
-    const float *__restrict__ v_render_alphas, int absgrad, float *__restrict__ v_geom,
-    float *__restrict__ v_colors) {
+    const int32_t *__restrict__ last_ids, const float *__restrict__ render_colors, int ed_channel,
+    const float *__restrict__ v_render_colors, const float *__restrict__ v_render_alphas, int absgrad,
+    float *__restrict__ v_geom, float *__restrict__ v_colors) {
   using Rg = Region<TS, PPL>;
   constexpr int ROW = color_row(CD);
   constexpr int CDP = round4(CD);
@@ -80,8 +80,20 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         for (int k = 0; k < CD; ++k)
           if (k < nch) vout[j][k] = src[k];
       }
+      float w_ed = 0.f;
+      if (ed_channel >= 0) {
+        // out_d = X / max(a, 1e-10): the cotangent of the accumulated depth X is v_out_d / a, and the
+        // direct dependence on a adds -v_out_d * out_d / a to the alpha cotangent (none when clamped).
+        const float a = 1.f - T[j], inv = 1.f / fmaxf(a, 1e-10f);
+#pragma unroll
+        for (int k = 0; k < CD; ++k)
+          if (k + ch_off == ed_channel) {
+            if (a > 1e-10f) w_ed = -vout[j][k] * render_colors[pix * D + ed_channel] * inv;
+            vout[j][k] *= inv;
+          }
+      }
       if (GEOM) {
-        float w = v_render_alphas[pix];
+        float w = v_render_alphas[pix] + w_ed;
         if (backgrounds) {
           const float *bg = backgrounds + (int64_t)cam * D + ch_off;
 #pragma unroll
@@ -234,14 +246,15 @@ template <int TS, int PPL, int CD, bool GEOM>
 static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const float *colors,
                       const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
                       const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
-                      const float *render_alphas, const int32_t *last_ids, const float *v_render_colors,
-                      const float *v_render_alphas, int absgrad, float *v_geom, float *v_colors, hipStream_t stream) {
+                      const float *render_alphas, const int32_t *last_ids, const float *render_colors,
+                      int ed_channel, const float *v_render_colors, const float *v_render_alphas, int absgrad,
+                      float *v_geom, float *v_colors, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
   const unsigned grid = (unsigned)((n_regions + 3) / 4);
   hipLaunchKernelGGL((raster_bwd_kernel<TS, PPL, CD, GEOM>), dim3(grid), dim3(256), 0, stream, (int)n_regions, N, D,
                      ch_off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h,
-                     isect_offsets, flatten_ids, (int)n_isects, render_alphas, last_ids, v_render_colors,
-                     v_render_alphas, absgrad, v_geom, v_colors);
+                     isect_offsets, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel,
+                     v_render_colors, v_render_alphas, absgrad, v_geom, v_colors);
   return check_launch("raster_bwd_kernel");
 }
 
@@ -260,8 +273,8 @@ extern "C" int pr_max_channels(void) { return 100; }
 
 #define BWD_ARGS                                                                                                     \
   C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,       \
-      flatten_ids, n_isects, render_alphas, last_ids, v_render_colors, v_render_alphas, absgrad, v_geom, v_colors,   \
-      (hipStream_t)stream
+      flatten_ids, n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas,   \
+      absgrad, v_geom, v_colors, (hipStream_t)stream
 #define BWD_CASE(TS, PPL, CDV)                                      \
   case CDV:                                                         \
     rc = geom_grad ? launch_bwd<TS, PPL, CDV, true>(BWD_ARGS)       \
@@ -272,7 +285,7 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
                              const float *opacities, const float *backgrounds, int width, int height, int tile_size,
                              int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
                              int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
-                             const float *v_render_colors, const float *v_render_alphas, int absgrad, int geom_grad,
+                             const float *render_colors, int ed_channel, const float *v_render_colors, const float *v_render_alphas, int absgrad, int geom_grad,
                              float *v_geom, float *v_colors, void *stream) {
   if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)
     return PR_EINVAL;
@@ -284,6 +297,7 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
       !v_render_colors || !v_render_alphas)
     return PR_EINVAL;
   if (geom_grad && !v_geom) return PR_EINVAL;
+  if (ed_channel >= D || (ed_channel >= 0 && !render_colors)) return PR_EINVAL;
   if (!geom_grad && !v_colors) return PR_OK;
   if ((int64_t)C * tile_w * tile_h * 4 > 2147483647ll) return PR_EUNSUPPORTED;
   // Geometry gradients need the dot product over ALL channels in one pass; colour-only gradients can

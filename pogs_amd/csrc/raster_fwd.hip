@@ -8,7 +8,7 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
-    const int32_t *__restrict__ flatten_ids, int n_isects, float *__restrict__ render_colors,
+    const int32_t *__restrict__ flatten_ids, int n_isects, int ed_channel, float *__restrict__ render_colors,
     float *__restrict__ render_alphas, int32_t *__restrict__ last_ids) {
   using Rg = Region<TS, PPL>;
   constexpr int ROW = color_row(CD);
@@ -125,6 +125,12 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
       for (int k = 0; k < CD; ++k)
         if (k < nch) acc[j][k] = fmaf(T[j], bg[k], acc[j][k]);
     }
+    if (ed_channel >= 0) {  // expected depth: accumulated depth / max(alpha, 1e-10)
+      const float inv = 1.f / fmaxf(1.f - T[j], 1e-10f);
+#pragma unroll
+      for (int k = 0; k < CD; ++k)
+        if (k + ch_off == ed_channel) acc[j][k] *= inv;
+    }
     if (((D | ch_off) & 3) == 0) {
 #pragma unroll
       for (int k = 0; k + 3 < CD; k += 4)
@@ -144,13 +150,13 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 template <int TS, int PPL, int CD>
 static int launch_fwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const float *colors,
                       const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
-                      const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects, float *render_colors,
-                      float *render_alphas, int32_t *last_ids, hipStream_t stream) {
+                      const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects, int ed_channel,
+                      float *render_colors, float *render_alphas, int32_t *last_ids, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
   const unsigned grid = (unsigned)((n_regions + 3) / 4);
   hipLaunchKernelGGL((raster_fwd_kernel<TS, PPL, CD>), dim3(grid), dim3(256), 0, stream, (int)n_regions, N, D, ch_off,
                      means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
-                     flatten_ids, (int)n_isects, render_colors, render_alphas, last_ids);
+                     flatten_ids, (int)n_isects, ed_channel, render_colors, render_alphas, last_ids);
   return check_launch("raster_fwd_kernel");
 }
 
@@ -171,20 +177,21 @@ using namespace pr;
 #define FWD_CASE(TS, PPL, CDV)                                                                                        \
   case CDV:                                                                                                           \
     rc = launch_fwd<TS, PPL, CDV>(C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height,       \
-                                  tile_w, tile_h, isect_offsets, flatten_ids, n_isects, render_colors, render_alphas, \
-                                  last_ids, (hipStream_t)stream);                                                     \
+                                  tile_w, tile_h, isect_offsets, flatten_ids, n_isects, ed_channel, render_colors,    \
+                                  render_alphas, last_ids, (hipStream_t)stream);                                      \
     break;
 
 extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
                              const float *opacities, const float *backgrounds, int width, int height, int tile_size,
                              int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
-                             int64_t n_isects, float *render_colors, float *render_alphas, int32_t *last_ids,
-                             void *stream) {
+                             int64_t n_isects, int ed_channel, float *render_colors, float *render_alphas,
+                             int32_t *last_ids, void *stream) {
   if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)
     return PR_EINVAL;
   if (tile_size != 16 && tile_size != 8) return PR_EUNSUPPORTED;
   if (D > pr_max_channels() || n_isects > 2147483647ll) return PR_EUNSUPPORTED;
   if ((int64_t)tile_w * tile_size < width || (int64_t)tile_h * tile_size < height) return PR_EINVAL;
+  if (ed_channel >= D) return PR_EINVAL;
   if (C == 0) return PR_OK;
   if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return PR_EINVAL;
   if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return PR_EINVAL;

@@ -232,7 +232,7 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size, isect_offsets,
-                flatten_ids, absgrad):
+                flatten_ids, absgrad, ed_channel):
         lib = _lib.load()
         C, N, D = colors.shape
         dev = means2d.device
@@ -246,11 +246,11 @@ class _Rasterize(torch.autograd.Function):
         with torch.cuda.device(dev):
             _call("pr_raster_fwd", C, N, D, _ptr(means2d_c), _ptr(conics), _ptr(colors), _ptr(opacities),
                                          _ptr(backgrounds), width, height, tile_size, tw, th, _ptr(isect_offsets),
-                                         _ptr(flatten_ids), flatten_ids.numel(), _ptr(render_colors),
+                                         _ptr(flatten_ids), flatten_ids.numel(), ed_channel, _ptr(render_colors),
                                          _ptr(render_alphas), _ptr(last_ids), _stream())
         ctx.save_for_backward(means2d_c, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids,
-                              render_alphas, last_ids)
-        ctx.args = (width, height, tile_size, absgrad)
+                              render_alphas, last_ids, render_colors if ed_channel >= 0 else None)
+        ctx.args = (width, height, tile_size, absgrad, ed_channel)
         ctx.means2d_obj = means2d  # the object callers hold in meta["means2d"]; receives .absgrad
         return render_colors, render_alphas
 
@@ -258,8 +258,8 @@ class _Rasterize(torch.autograd.Function):
     def backward(ctx, v_render_colors, v_render_alphas):
         lib = _lib.load()
         (means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, render_alphas,
-         last_ids) = ctx.saved_tensors
-        width, height, tile_size, absgrad = ctx.args
+         last_ids, render_colors) = ctx.saved_tensors
+        width, height, tile_size, absgrad, ed_channel = ctx.args
         C, N, D = colors.shape
         dev = means2d.device
         th, tw = isect_offsets.shape[1:]
@@ -277,9 +277,9 @@ class _Rasterize(torch.autograd.Function):
                 _call("pr_raster_bwd", C, N, D, _ptr(means2d), _ptr(conics), _ptr(colors), _ptr(opacities),
                                              _ptr(backgrounds), width, height, tile_size, tw, th,
                                              _ptr(isect_offsets), _ptr(flatten_ids), flatten_ids.numel(),
-                                             _ptr(render_alphas), _ptr(last_ids), _ptr(v_render_colors),
-                                             _ptr(v_render_alphas), int(absgrad), int(geom), _ptr(v_geom),
-                                             _ptr(v_colors), _stream())
+                                             _ptr(render_alphas), _ptr(last_ids), _ptr(render_colors), ed_channel,
+                                             _ptr(v_render_colors), _ptr(v_render_alphas), int(absgrad),
+                                             int(geom), _ptr(v_geom), _ptr(v_colors), _stream())
         v_means2d = v_conics = v_opacities = None
         if geom:
             g = v_geom.view(C, N, 8)
@@ -289,19 +289,96 @@ class _Rasterize(torch.autograd.Function):
         v_backgrounds = None
         if backgrounds is not None and ctx.needs_input_grad[4]:
             v_backgrounds = (v_render_colors * (1.0 - render_alphas)).sum(dim=(1, 2))
+            if ed_channel >= 0:
+                v_backgrounds[:, ed_channel] = (v_render_colors[..., ed_channel] * (1.0 - render_alphas[..., 0])
+                                                / render_alphas[..., 0].clamp(min=1e-10)).sum(dim=(1, 2))
         ctx.means2d_obj = None
         return (v_means2d if ctx.needs_input_grad[0] else None, v_conics if ctx.needs_input_grad[1] else None,
                 v_colors, v_opacities if ctx.needs_input_grad[3] else None, v_backgrounds, None, None, None, None,
-                None, None)
+                None, None, None)
 
 
 def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor, image_width: int,
                         image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
-                        backgrounds: Optional[Tensor] = None, absgrad: bool = False) -> Tuple[Tensor, Tensor]:
+                        backgrounds: Optional[Tensor] = None, absgrad: bool = False,
+                        ed_channel: int = -1) -> Tuple[Tensor, Tensor]:
     """Stands in for gsplat ``rasterize_to_pixels`` (non-packed): [C,N,*] inputs ->
-    render_colors [C,H,W,D], render_alphas [C,H,W,1]."""
+    render_colors [C,H,W,D], render_alphas [C,H,W,1].  ``ed_channel`` (extension): index of a depth
+    channel to output as expected depth, accumulated depth / max(alpha, 1e-10); -1 = none."""
     return _Rasterize.apply(means2d, conics, colors, opacities, backgrounds, image_width, image_height, tile_size,
-                            isect_offsets, flatten_ids, absgrad)
+                            isect_offsets, flatten_ids, absgrad, int(ed_channel))
+
+
+class _AssembleColors(torch.autograd.Function):
+    """Builds the per-Gaussian channel buffer the compositor reads, [C,N,D] = [rgb | features | depth], in
+    place: SH colours are evaluated straight into columns 0..2 (or given colours copied there), features and
+    depths are strided copies.  Backward hands out column views of the incoming gradient -- no concatenation
+    or split copies either way."""
+
+    @staticmethod
+    def forward(ctx, sh_degree, means, campos, colors, radii, features, depths, C):
+        N = means.shape[0]
+        dev = means.device
+        n_col = 0 if colors is None else (3 if sh_degree is not None else colors.shape[-1])
+        n_feat = 0 if features is None else features.shape[-1]
+        n_dep = 0 if depths is None else 1
+        D = n_col + n_feat + n_dep
+        out = torch.empty(C, N, D, dtype=torch.float32, device=dev)
+        coeffs = None
+        if colors is not None:
+            if sh_degree is not None:
+                coeffs = colors.contiguous()
+                means_c, campos_c = means.contiguous(), campos.contiguous()
+                with torch.cuda.device(dev):
+                    _call("pr_sh_fwd", C, N, coeffs.shape[1], sh_degree, _ptr(means_c), _ptr(campos_c), _ptr(coeffs),
+                          _ptr(radii), 1, _ptr(out), D, _stream())
+                ctx.save_for_backward(means_c, campos_c, coeffs, radii)
+            else:
+                out[..., :n_col].copy_(colors if colors.dim() == 3 else colors[None].expand(C, -1, -1))
+        if features is not None:
+            out[..., n_col:n_col + n_feat].copy_(features[None].expand(C, -1, -1))
+        if depths is not None:
+            out[..., D - 1].copy_(depths)
+        ctx.layout = (sh_degree, n_col, n_feat, n_dep, C, N, None if colors is None else colors.dim())
+        return out
+
+    @staticmethod
+    def backward(ctx, v_out):
+        sh_degree, n_col, n_feat, n_dep, C, N, colors_dim = ctx.layout
+        D = n_col + n_feat + n_dep
+        dev = v_out.device
+        v_means = v_campos = v_colors = v_features = v_depths = None
+        if n_col and ctx.needs_input_grad[3]:
+            if sh_degree is not None:
+                means, campos, coeffs, radii = ctx.saved_tensors
+                K = coeffs.shape[1]
+                v, ld = _rows(v_out, D)
+                v_colors = torch.empty(N, K, 3, dtype=torch.float32, device=dev)
+                v_means = torch.empty(N, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+                v_campos = torch.zeros(C, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+                with torch.cuda.device(dev):
+                    _call("pr_sh_bwd", C, N, K, sh_degree, _ptr(means), _ptr(campos), _ptr(coeffs), _ptr(radii), 1,
+                          _ptr(v), ld, _ptr(v_colors), _ptr(v_means), _ptr(v_campos), _stream())
+            else:
+                v_colors = v_out[..., :n_col]
+                if colors_dim == 2:
+                    v_colors = v_colors[0] if C == 1 else v_colors.sum(0)
+        elif n_col and sh_degree is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            means, campos, coeffs, radii = ctx.saved_tensors
+            K = coeffs.shape[1]
+            v, ld = _rows(v_out, D)
+            scratch = torch.empty(N, K, 3, dtype=torch.float32, device=dev)
+            v_means = torch.empty(N, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+            v_campos = torch.zeros(C, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+            with torch.cuda.device(dev):
+                _call("pr_sh_bwd", C, N, K, sh_degree, _ptr(means), _ptr(campos), _ptr(coeffs), _ptr(radii), 1,
+                      _ptr(v), ld, _ptr(scratch), _ptr(v_means), _ptr(v_campos), _stream())
+        if n_feat and ctx.needs_input_grad[5]:
+            v_features = v_out[..., n_col:n_col + n_feat]
+            v_features = v_features[0] if C == 1 else v_features.sum(0)
+        if n_dep and ctx.needs_input_grad[6]:
+            v_depths = v_out[..., D - 1]
+        return None, v_means, v_campos, v_colors, None, v_features, v_depths, None
 
 
 def fully_fused_projection(means, quats, scales, viewmats, Ks, width, height, eps2d=0.3, near_plane=0.01,
@@ -392,27 +469,27 @@ def rasterization(
     if compensations is not None:
         opac = opac * compensations
 
-    if sh_degree is None:
-        cols = colors[None].expand(C, -1, -1) if colors.dim() == 2 else colors
-    else:
+    if features is not None:
+        assert features.dim() == 2 and features.shape[0] == N, features.shape
+    with_depth = render_mode in ("RGB+D", "RGB+ED", "D", "ED")
+    depth_only = render_mode in ("D", "ED")
+    campos = None
+    if sh_degree is not None and not depth_only:
         if colors.dim() == 4:
             if C != 1:
                 raise NotImplementedError("per-camera SH coefficients with C > 1")
             colors = colors[0]
-        cols = _SphericalHarmonics.apply(int(sh_degree), means, camera_centers(viewmats), colors, radii, True)
-    if features is not None:
-        assert features.dim() == 2 and features.shape[0] == N, features.shape
-        cols = torch.cat([cols, features[None].expand(C, -1, -1)], dim=-1)
+        campos = camera_centers(viewmats)
+    # one buffer [C,N,D] = [rgb or given colours | features | depth], written in place (no concatenations)
+    cols = _AssembleColors.apply(
+        None if sh_degree is None else int(sh_degree), means, campos, None if depth_only else colors, radii,
+        None if depth_only else features, depths if with_depth else None, C)
     bgs = backgrounds
-    if render_mode in ("RGB+D", "RGB+ED"):
-        cols = torch.cat([cols, depths[..., None]], dim=-1)
-        if bgs is not None:
-            bgs = torch.cat([bgs, torch.zeros(C, 1, device=bgs.device, dtype=bgs.dtype)], dim=-1)
-    elif render_mode in ("D", "ED"):
-        cols = depths[..., None]
-        if bgs is not None:
-            bgs = torch.zeros(C, 1, device=bgs.device, dtype=bgs.dtype)
     if bgs is not None:
+        if depth_only:
+            bgs = torch.zeros(C, 1, device=bgs.device, dtype=bgs.dtype)
+        elif with_depth:
+            bgs = torch.cat([bgs, torch.zeros(C, 1, device=bgs.device, dtype=bgs.dtype)], dim=-1)
         assert bgs.shape == (C, cols.shape[-1]), bgs.shape
 
     tile_width = math.ceil(width / float(tile_size))
@@ -420,12 +497,11 @@ def rasterization(
     tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height)
     isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
 
+    # expected depth (ED): the depth channel is divided by max(alpha, 1e-10) inside the kernels
+    ed_channel = cols.shape[-1] - 1 if render_mode in ("ED", "RGB+ED") else -1
     render_colors, render_alphas = rasterize_to_pixels(
         means2d, conics, cols, opac, width, height, tile_size, isect_offsets, flatten_ids, backgrounds=bgs,
-        absgrad=absgrad)
-    if render_mode in ("ED", "RGB+ED"):
-        render_colors = torch.cat(
-            [render_colors[..., :-1], render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
+        absgrad=absgrad, ed_channel=ed_channel)
 
     meta = {
         "camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths,
