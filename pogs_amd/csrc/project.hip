@@ -420,14 +420,72 @@ __device__ __forceinline__ void sh_bases_grad(int nb, float x, float y, float z,
   }
 }
 
+// Coefficient rows are 3K floats per Gaussian; a lane reading its own row touches 64 different cache
+// lines per load instruction.  For K = 16 (the only case POGS uses) a wavefront instead moves the 64 rows
+// it owns as ONE contiguous 12 KiB block of 16-byte accesses and transposes through its LDS slice
+// (52-float pitch: 16-byte aligned rows whose 16-byte reads by 16 consecutive lanes hit distinct banks).
+constexpr int SH_ROW = 48, SH_PITCH = 52;
+
+__device__ __forceinline__ void wave_rows48_load(const float *__restrict__ src, int64_t row0, int64_t n_rows,
+                                                 float *lds, int lane, float *out) {
+  const float4 *s4 = reinterpret_cast<const float4 *>(src + row0 * SH_ROW);
+  const int64_t avail4 = (n_rows - row0) * (SH_ROW / 4);
+#pragma unroll
+  for (int i = 0; i < SH_ROW / 4; ++i) {
+    const int idx4 = i * 64 + lane;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx4 < avail4) v = s4[idx4];
+    const int row = idx4 / (SH_ROW / 4), col4 = idx4 % (SH_ROW / 4);
+    *reinterpret_cast<float4 *>(lds + row * SH_PITCH + 4 * col4) = v;
+  }
+#pragma unroll
+  for (int i = 0; i < SH_ROW / 4; ++i) {
+    const float4 v = *reinterpret_cast<const float4 *>(lds + lane * SH_PITCH + 4 * i);
+    out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ void wave_rows48_store(float *__restrict__ dst, int64_t row0, int64_t n_rows, float *lds,
+                                                  int lane, const float *in) {
+#pragma unroll
+  for (int i = 0; i < SH_ROW / 4; ++i)
+    *reinterpret_cast<float4 *>(lds + lane * SH_PITCH + 4 * i) =
+        make_float4(in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3]);
+  float4 *d4 = reinterpret_cast<float4 *>(dst + row0 * SH_ROW);
+  const int64_t avail4 = (n_rows - row0) * (SH_ROW / 4);
+#pragma unroll
+  for (int i = 0; i < SH_ROW / 4; ++i) {
+    const int idx4 = i * 64 + lane;
+    const int row = idx4 / (SH_ROW / 4), col4 = idx4 % (SH_ROW / 4);
+    const float4 v = *reinterpret_cast<const float4 *>(lds + row * SH_PITCH + 4 * col4);
+    if (idx4 < avail4) d4[idx4] = v;
+  }
+}
+
+// grid = (ceil(N/256), C): block (b, c) handles Gaussians [256 b, 256 b + 256) of camera c.
+template <bool K16>
 __global__ void __launch_bounds__(256) sh_fwd_kernel(int C, int N, int K, int nb, const float *__restrict__ means,
                                                      const float *__restrict__ campos,
                                                      const float *__restrict__ coeffs,
                                                      const int32_t *__restrict__ radii, int post,
                                                      float *__restrict__ colors, int ld) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)C * N) return;
-  int c = (int)(idx / N), n = (int)(idx % N);
+  __shared__ float lds[K16 ? 4 * 64 * SH_PITCH : 4];
+  const int c = blockIdx.y;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = n < N;
+  const int nn = live ? n : 0;
+  float cf[48];
+  if (K16) {
+    const int64_t row0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    if (row0 < N) wave_rows48_load(coeffs, row0, N, lds + wave * 64 * SH_PITCH, lane, cf);
+  } else {
+    const float *src = coeffs + (int64_t)nn * K * 3;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) cf[i] = (i < 3 * nb) ? src[i] : 0.f;
+  }
+  if (!live) return;
+  const int64_t idx = (int64_t)c * N + n;
   float r = 0.f, g = 0.f, bl = 0.f;
   if (radii[idx] > 0) {
     float dx = means[3 * n] - campos[3 * c], dy = means[3 * n + 1] - campos[3 * c + 1],
@@ -435,12 +493,13 @@ __global__ void __launch_bounds__(256) sh_fwd_kernel(int C, int N, int K, int nb
     float inv = 1.f / fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
     float b[16];
     sh_bases(nb, dx * inv, dy * inv, dz * inv, b);
-    const float *cf = coeffs + (int64_t)n * K * 3;
-    for (int i = 0; i < nb; ++i) {
-      r += b[i] * cf[3 * i];
-      g += b[i] * cf[3 * i + 1];
-      bl += b[i] * cf[3 * i + 2];
-    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < nb) {
+        r += b[i] * cf[3 * i];
+        g += b[i] * cf[3 * i + 1];
+        bl += b[i] * cf[3 * i + 2];
+      }
   }
   if (post) {
     r = fmaxf(r + 0.5f, 0.f);
@@ -451,6 +510,7 @@ __global__ void __launch_bounds__(256) sh_fwd_kernel(int C, int N, int K, int nb
   o[0] = r; o[1] = g; o[2] = bl;
 }
 
+template <bool K16>
 __global__ void __launch_bounds__(256) sh_bwd_kernel(int C, int N, int K, int nb, const float *__restrict__ means,
                                                      const float *__restrict__ campos,
                                                      const float *__restrict__ coeffs,
@@ -459,10 +519,20 @@ __global__ void __launch_bounds__(256) sh_bwd_kernel(int C, int N, int K, int nb
                                                      float *__restrict__ v_coeffs, float *__restrict__ v_means,
                                                      float *__restrict__ v_campos) {
   __shared__ float red[4];
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
-  bool live = n < N;
-  int nn = live ? n : 0;
-  const float *cf = coeffs + (int64_t)nn * K * 3;
+  __shared__ float lds[K16 ? 4 * 64 * SH_PITCH : 4];
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = n < N;
+  const int nn = live ? n : 0;
+  const int64_t row0 = (int64_t)blockIdx.x * 256 + wave * 64;
+  float cf[48];
+  if (K16) {
+    if (row0 < N) wave_rows48_load(coeffs, row0, N, lds + wave * 64 * SH_PITCH, lane, cf);
+  } else {
+    const float *src = coeffs + (int64_t)nn * K * 3;
+#pragma unroll
+    for (int i = 0; i < 48; ++i) cf[i] = (i < 3 * nb) ? src[i] : 0.f;
+  }
   float vcf[48];
 #pragma unroll
   for (int i = 0; i < 48; ++i) vcf[i] = 0.f;
@@ -480,11 +550,13 @@ __global__ void __launch_bounds__(256) sh_bwd_kernel(int C, int N, int K, int nb
       float vc[3] = {v_colors[idx * ld], v_colors[idx * ld + 1], v_colors[idx * ld + 2]};
       if (post) {
         float col[3] = {0.5f, 0.5f, 0.5f};
-        for (int i = 0; i < nb; ++i) {
-          col[0] += b[i] * cf[3 * i];
-          col[1] += b[i] * cf[3 * i + 1];
-          col[2] += b[i] * cf[3 * i + 2];
-        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (i < nb) {
+            col[0] += b[i] * cf[3 * i];
+            col[1] += b[i] * cf[3 * i + 1];
+            col[2] += b[i] * cf[3 * i + 2];
+          }
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           if (col[k] < 0.f) vc[k] = 0.f;
@@ -519,13 +591,15 @@ __global__ void __launch_bounds__(256) sh_bwd_kernel(int C, int N, int K, int nb
       for (int k = 0; k < 3; ++k) block_atomic_add(-vdir[k], v_campos + 3 * c + k, red);
     }
   }
-  if (!live) return;
-  float *o = v_coeffs + (int64_t)n * K * 3;
+  if (K16) {
+    if (row0 < N) wave_rows48_store(v_coeffs, row0, N, lds + wave * 64 * SH_PITCH, lane, vcf);
+  } else if (live) {
+    float *o = v_coeffs + (int64_t)n * K * 3;
 #pragma unroll
-  for (int i = 0; i < 48; ++i)
-    if (i < 3 * K) o[i] = vcf[i];
-  for (int i = 48; i < 3 * K; ++i) o[i] = 0.f;
-  if (v_means) {
+    for (int i = 0; i < 48; ++i)
+      if (i < 3 * K) o[i] = vcf[i];
+  }
+  if (live && v_means) {
     v_means[3 * n] = vm[0];
     v_means[3 * n + 1] = vm[1];
     v_means[3 * n + 2] = vm[2];
@@ -578,10 +652,14 @@ extern "C" int pr_sh_fwd(int C, int N, int K, int degree, const float *means, co
   if (nb > K) return PR_EINVAL;
   if ((int64_t)C * N == 0) return PR_OK;
   if (!means || !campos || !coeffs || !radii || !colors) return PR_EINVAL;
-  int64_t total = (int64_t)C * N;
-  unsigned grid = (unsigned)((total + 255) / 256);
-  hipLaunchKernelGGL(sh_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, K, nb, means, campos, coeffs,
-                     radii, post, colors, ld_colors);
+  if (C > 65535) return PR_EUNSUPPORTED;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)C);
+  if (K == 16)
+    hipLaunchKernelGGL(sh_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, C, N, K, nb, means, campos,
+                       coeffs, radii, post, colors, ld_colors);
+  else
+    hipLaunchKernelGGL(sh_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, C, N, K, nb, means, campos,
+                       coeffs, radii, post, colors, ld_colors);
   return check_launch("sh_fwd_kernel");
 }
 
@@ -595,7 +673,11 @@ extern "C" int pr_sh_bwd(int C, int N, int K, int degree, const float *means, co
   if (N == 0) return PR_OK;
   if (!means || !campos || !coeffs || !radii || !v_colors || !v_coeffs) return PR_EINVAL;
   unsigned grid = (unsigned)((N + 255) / 256);
-  hipLaunchKernelGGL(sh_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, K, nb, means, campos, coeffs,
-                     radii, post, v_colors, ld_colors, v_coeffs, v_means, v_campos);
+  if (K == 16)
+    hipLaunchKernelGGL(sh_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, K, nb, means, campos,
+                       coeffs, radii, post, v_colors, ld_colors, v_coeffs, v_means, v_campos);
+  else
+    hipLaunchKernelGGL(sh_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, K, nb, means,
+                       campos, coeffs, radii, post, v_colors, ld_colors, v_coeffs, v_means, v_campos);
   return check_launch("sh_bwd_kernel");
 }
