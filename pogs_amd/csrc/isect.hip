@@ -1,5 +1,5 @@
-// Tile-intersection binning for gfx950: per-Gaussian tile counts + prefix sum, key/value emission,
-// stable device radix sort (rocPRIM, restricted to the significant key bits), per-tile offsets.
+// Tile-intersection binning for gfx950: per-Gaussian tile counts + prefix sum, depth-ordered key/value
+// emission, stable device radix sorts (rocPRIM, restricted to the significant key bits), per-tile offsets.
 //
 // Integer work; results must be bit-identical to the CPU restatement, so the tile rectangle is
 // computed with true float32 divisions (no reciprocal multiply that could be contracted into an FMA).
@@ -39,33 +39,6 @@ __global__ void __launch_bounds__(256) isect_count_kernel(int64_t total, const f
     cnt = (t.x1 - t.x0) * (t.y1 - t.y0);
   }
   tiles_per_gauss[idx] = cnt;
-}
-
-__global__ void __launch_bounds__(256) isect_emit_kernel(int64_t total, int N, const float *__restrict__ means2d,
-                                                         const int32_t *__restrict__ radii,
-                                                         const float *__restrict__ depths,
-                                                         const int64_t *__restrict__ cum_tiles, float ts, int tile_w,
-                                                         int tile_h, int tile_bits, int64_t n_isects,
-                                                         int64_t *__restrict__ keys, int32_t *__restrict__ vals) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  int r = radii[idx];
-  if (r <= 0) return;
-  TileRect t = tile_rect(means2d[2 * idx], means2d[2 * idx + 1], r, ts, tile_w, tile_h);
-  int cnt = (t.x1 - t.x0) * (t.y1 - t.y0);
-  if (cnt <= 0) return;
-  int64_t k = cum_tiles[idx] - cnt;
-  int64_t cam = idx / N;
-  int64_t dbits = (int64_t)(uint32_t)__float_as_int(depths[idx]);
-  int64_t hi = cam << tile_bits;
-  for (int y = t.y0; y < t.y1; ++y)
-    for (int x = t.x0; x < t.x1; ++x) {
-      if (k < n_isects) {
-        keys[k] = ((hi | (int64_t)(y * tile_w + x)) << 32) | dbits;
-        vals[k] = (int32_t)idx;
-      }
-      ++k;
-    }
 }
 
 __global__ void __launch_bounds__(256) isect_offsets_kernel(int64_t n_isects, const int64_t *__restrict__ isect_ids,
@@ -136,47 +109,142 @@ extern "C" int pr_isect_count(int C, int N, const float *means2d, const int32_t 
   return PR_OK;
 }
 
-static size_t sort_temp_bytes(int64_t n_isects) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int64_t *)nullptr, (int64_t *)nullptr, (const int32_t *)nullptr,
-                            (int32_t *)nullptr, (size_t)n_isects, 0u, 64u);
-  return bytes;
+// ---- phase 2: two-level stable sort -----------------------------------------------------------------
+// The reference sorts 64-bit keys (camera | tile | depth bits) over all intersections: ceil((32+tb+cb)/8)
+// radix passes over I pairs.  The same order is reached with far less traffic by sorting the C*N
+// GAUSSIANS by depth bits first (stable, so ties keep ascending flat index), emitting intersections in
+// that order with 32-bit (camera | tile) keys, and finishing with a stable sort over only the tb+cb tile
+// bits (2 passes of 8-byte pairs at 1080p instead of 6 passes of 12-byte pairs).
+struct Phase2Layout {
+  size_t dkeys_in, dkeys_out, dvals_in, dvals_out, starts, tkeys_in, tkeys_out, tvals_in, temp, temp_bytes, total;
+};
+
+struct TilesOf {
+  const int32_t *tpg;
+  __device__ __host__ uint32_t operator()(uint32_t flat) const { return (uint32_t)tpg[flat]; }
+};
+
+static Phase2Layout phase2_layout(int64_t cn, int64_t n_isects) {
+  Phase2Layout L;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += align256(bytes);
+    return o;
+  };
+  L.dkeys_in = take((size_t)cn * 4);
+  L.dkeys_out = take((size_t)cn * 4);
+  L.dvals_in = take((size_t)cn * 4);
+  L.dvals_out = take((size_t)cn * 4);
+  L.starts = take((size_t)cn * 4);
+  L.tkeys_in = take((size_t)n_isects * 4);
+  L.tkeys_out = take((size_t)n_isects * 4);
+  L.tvals_in = take((size_t)n_isects * 4);
+  size_t t1 = 0, t2 = 0, t3 = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, t1, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                  (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)cn, 0u, 32u);
+  (void)rocprim::radix_sort_pairs(nullptr, t2, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                  (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n_isects, 0u, 32u);
+  auto it = rocprim::make_transform_iterator((const uint32_t *)nullptr, TilesOf{nullptr});
+  (void)rocprim::exclusive_scan(nullptr, t3, it, (uint32_t *)nullptr, 0u, (size_t)cn, rocprim::plus<uint32_t>());
+  L.temp_bytes = t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3);
+  L.temp = take(L.temp_bytes);
+  L.total = off + 256;
+  return L;
+}
+
+__global__ void __launch_bounds__(256) depth_keys_kernel(int64_t total, const float *__restrict__ depths,
+                                                         const int32_t *__restrict__ tiles_per_gauss,
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  keys[idx] = tiles_per_gauss[idx] > 0 ? (uint32_t)__float_as_int(depths[idx]) : 0xFFFFFFFFu;
+  vals[idx] = (uint32_t)idx;
+}
+
+// One lane per Gaussian in depth order; writes its (camera|tile) keys and its flat index.
+__global__ void __launch_bounds__(256) isect_emit_sorted_kernel(
+    int64_t total, int N, const uint32_t *__restrict__ order, const uint32_t *__restrict__ starts,
+    const float *__restrict__ means2d, const int32_t *__restrict__ radii, float ts, int tile_w, int tile_h,
+    int tile_bits, int64_t n_isects, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= total) return;
+  const uint32_t idx = order[r];
+  const int rad = radii[idx];
+  if (rad <= 0) return;
+  TileRect t = tile_rect(means2d[2 * (int64_t)idx], means2d[2 * (int64_t)idx + 1], rad, ts, tile_w, tile_h);
+  if ((t.x1 - t.x0) * (t.y1 - t.y0) <= 0) return;
+  int64_t k = starts[r];
+  const uint32_t hi = (uint32_t)(idx / (uint32_t)N) << tile_bits;
+  for (int y = t.y0; y < t.y1; ++y)
+    for (int x = t.x0; x < t.x1; ++x) {
+      if (k < n_isects) {
+        keys[k] = hi | (uint32_t)(y * tile_w + x);
+        vals[k] = idx;
+      }
+      ++k;
+    }
+}
+
+__global__ void __launch_bounds__(256) isect_ids_kernel(int64_t n_isects, const uint32_t *__restrict__ tkeys,
+                                                        const int32_t *__restrict__ flatten_ids,
+                                                        const float *__restrict__ depths,
+                                                        int64_t *__restrict__ isect_ids) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_isects) return;
+  const uint32_t d = (uint32_t)__float_as_int(depths[flatten_ids[k]]);
+  isect_ids[k] = ((int64_t)tkeys[k] << 32) | (int64_t)d;
 }
 
 extern "C" size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects) {
-  (void)C;
-  (void)N;
-  if (n_isects <= 0) return 256;
-  return align256((size_t)n_isects * 8) + align256((size_t)n_isects * 4) + align256(sort_temp_bytes(n_isects)) + 256;
+  if (n_isects <= 0 || (int64_t)C * N <= 0) return 256;
+  return phase2_layout((int64_t)C * N, n_isects).total;
 }
 
 extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
-                                  const int64_t *cum_tiles, int tile_size, int tile_w, int tile_h, int64_t n_isects,
-                                  int64_t *isect_ids, int32_t *flatten_ids, void *scratch, size_t scratch_bytes,
-                                  void *stream) {
+                                  const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h,
+                                  int64_t n_isects, int64_t *isect_ids, int32_t *flatten_ids, void *scratch,
+                                  size_t scratch_bytes, void *stream) {
   if (C < 0 || N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0) return PR_EINVAL;
-  int64_t total = (int64_t)C * N;
+  const int64_t total = (int64_t)C * N;
   if (total == 0 || n_isects == 0) return PR_OK;
-  if (n_isects > (int64_t)2147483647) return PR_EUNSUPPORTED;  // offsets and last_ids are int32
-  if (!means2d || !radii || !depths || !cum_tiles || !isect_ids || !flatten_ids || !scratch) return PR_EINVAL;
-  size_t kb = align256((size_t)n_isects * 8), vb = align256((size_t)n_isects * 4);
-  size_t tb = sort_temp_bytes(n_isects);
-  if (kb + vb + tb > scratch_bytes) return PR_ESCRATCH;
-  int64_t *keys = (int64_t *)scratch;
-  int32_t *vals = (int32_t *)((char *)scratch + kb);
-  void *temp = (char *)scratch + kb + vb;
-  int tile_bits = bit_length((int64_t)tile_w * tile_h);
-  int cam_bits = bit_length((int64_t)C - 1);
-  unsigned grid = (unsigned)((total + 255) / 256);
-  hipLaunchKernelGGL(isect_emit_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, total, N, means2d, radii,
-                     depths, cum_tiles, (float)tile_size, tile_w, tile_h, tile_bits, n_isects, keys, vals);
-  int rc = check_launch("isect_emit_kernel");
+  if (n_isects > (int64_t)2147483647 || total > (int64_t)2147483647) return PR_EUNSUPPORTED;
+  if (!means2d || !radii || !depths || !tiles_per_gauss || !isect_ids || !flatten_ids || !scratch) return PR_EINVAL;
+  const int tile_bits = bit_length((int64_t)tile_w * tile_h);
+  const int cam_bits = bit_length((int64_t)C - 1);
+  if (tile_bits + cam_bits > 32) return PR_EUNSUPPORTED;
+  const Phase2Layout L = phase2_layout(total, n_isects);
+  if (L.total > scratch_bytes) return PR_ESCRATCH;
+  char *base = (char *)scratch;
+  uint32_t *dk_in = (uint32_t *)(base + L.dkeys_in), *dk_out = (uint32_t *)(base + L.dkeys_out);
+  uint32_t *dv_in = (uint32_t *)(base + L.dvals_in), *dv_out = (uint32_t *)(base + L.dvals_out);
+  uint32_t *starts = (uint32_t *)(base + L.starts);
+  uint32_t *tk_in = (uint32_t *)(base + L.tkeys_in), *tk_out = (uint32_t *)(base + L.tkeys_out);
+  uint32_t *tv_in = (uint32_t *)(base + L.tvals_in);
+  void *temp = base + L.temp;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid_n = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(depth_keys_kernel, dim3(grid_n), dim3(256), 0, st, total, depths, tiles_per_gauss, dk_in, dv_in);
+  int rc = check_launch("depth_keys_kernel");
   if (rc) return rc;
-  unsigned end_bit = (unsigned)(32 + tile_bits + cam_bits);
-  if (end_bit > 64u) return PR_EUNSUPPORTED;
-  PR_HIP(rocprim::radix_sort_pairs(temp, tb, (const int64_t *)keys, isect_ids, (const int32_t *)vals, flatten_ids,
-                                   (size_t)n_isects, 0u, end_bit, (hipStream_t)stream));
-  return PR_OK;
+  size_t tb = L.temp_bytes;
+  PR_HIP(rocprim::radix_sort_pairs(temp, tb, (const uint32_t *)dk_in, dk_out, (const uint32_t *)dv_in, dv_out,
+                                   (size_t)total, 0u, 32u, st));
+  auto it = rocprim::make_transform_iterator((const uint32_t *)dv_out, TilesOf{tiles_per_gauss});
+  tb = L.temp_bytes;
+  PR_HIP(rocprim::exclusive_scan(temp, tb, it, starts, 0u, (size_t)total, rocprim::plus<uint32_t>(), st));
+  hipLaunchKernelGGL(isect_emit_sorted_kernel, dim3(grid_n), dim3(256), 0, st, total, N, dv_out, starts, means2d,
+                     radii, (float)tile_size, tile_w, tile_h, tile_bits, n_isects, tk_in, tv_in);
+  rc = check_launch("isect_emit_sorted_kernel");
+  if (rc) return rc;
+  tb = L.temp_bytes;
+  PR_HIP(rocprim::radix_sort_pairs(temp, tb, (const uint32_t *)tk_in, tk_out, (const uint32_t *)tv_in,
+                                   (uint32_t *)flatten_ids, (size_t)n_isects, 0u, (unsigned)(tile_bits + cam_bits),
+                                   st));
+  const unsigned grid_i = (unsigned)((n_isects + 255) / 256);
+  hipLaunchKernelGGL(isect_ids_kernel, dim3(grid_i), dim3(256), 0, st, n_isects, tk_out, flatten_ids, depths,
+                     isect_ids);
+  return check_launch("isect_ids_kernel");
 }
 
 extern "C" int pr_isect_offsets(int64_t n_isects, const int64_t *isect_ids, int C, int tile_w, int tile_h,

@@ -210,7 +210,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
         if n_isects > 0:
             nb = lib.pr_isect_sort_scratch_bytes(C, N, n_isects)
             scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-            _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(cum), tile_size,
+            _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(tiles_per_gauss), tile_size,
                                               tile_width, tile_height, n_isects, _ptr(isect_ids), _ptr(flatten_ids),
                                               _ptr(scratch), nb, _stream())
     return tiles_per_gauss, isect_ids, flatten_ids
