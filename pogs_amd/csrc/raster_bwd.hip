@@ -49,7 +49,9 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
   const int range_lo = isect_offsets[tile_flat];
   const int nch = min(CD, D - ch_off);
 
-  float T[PPL], Bsum[PPL], W[PPL], vout[PPL][CDP];
+  constexpr int CH2 = CDP / 2;  // channel pairs
+  float T[PPL], Bsum[PPL], W[PPL];
+  f2 vout[PPL][CH2];
   int last[PPL];
   const float px0 = (float)x0 + 0.5f, py0 = (float)y0 + 0.5f;
   int max_last = range_lo;
@@ -63,7 +65,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     W[j] = 0.f;
     last[j] = range_lo;
 #pragma unroll
-    for (int k = 0; k < CDP; ++k) vout[j][k] = 0.f;
+    for (int k = 0; k < CH2; ++k) vout[j][k] = splat(0.f);
     if (inside) {
       T[j] = 1.f - render_alphas[pix];
       last[j] = last_ids[pix];
@@ -73,12 +75,13 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         for (int k = 0; k + 3 < CDP; k += 4)
           if (k < nch) {
             const float4 v = *reinterpret_cast<const float4 *>(src + k);
-            vout[j][k] = v.x; vout[j][k + 1] = v.y; vout[j][k + 2] = v.z; vout[j][k + 3] = v.w;
+            vout[j][k / 2] = f2{v.x, v.y};
+            vout[j][k / 2 + 1] = f2{v.z, v.w};
           }
       } else {
 #pragma unroll
         for (int k = 0; k < CD; ++k)
-          if (k < nch) vout[j][k] = src[k];
+          if (k < nch) vout[j][k / 2][k % 2] = src[k];
       }
       float w_ed = 0.f;
       if (ed_channel >= 0) {
@@ -88,8 +91,8 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 #pragma unroll
         for (int k = 0; k < CD; ++k)
           if (k + ch_off == ed_channel) {
-            if (a > 1e-10f) w_ed = -vout[j][k] * render_colors[pix * D + ed_channel] * inv;
-            vout[j][k] *= inv;
+            if (a > 1e-10f) w_ed = -vout[j][k / 2][k % 2] * render_colors[pix * D + ed_channel] * inv;
+            vout[j][k / 2][k % 2] *= inv;
           }
       }
       if (GEOM) {
@@ -98,7 +101,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
           const float *bg = backgrounds + (int64_t)cam * D + ch_off;
 #pragma unroll
           for (int k = 0; k < CD; ++k)
-            if (k < nch) w -= bg[k] * vout[j][k];
+            if (k < nch) w -= bg[k] * vout[j][k / 2][k % 2];
         }
         W[j] = T[j] * w;
       }
@@ -166,9 +169,9 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         T[j] = active[j] ? T[j] * ra[j] : T[j];
         fac[j] = active[j] ? alpha[j] * T[j] : 0.f;
       }
-      float S[PPL];
+      f2 S2[PPL];
 #pragma unroll
-      for (int j = 0; j < PPL; ++j) S[j] = 0.f;
+      for (int j = 0; j < PPL; ++j) S2[j] = splat(0.f);
       const float4 *crow = reinterpret_cast<const float4 *>(L.col + t * ROW);
       const int gid = L.ids[t];
       float *red = L.red;
@@ -176,22 +179,24 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
       for (int q = 0; q < NQ; ++q) {
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (GEOM) c4 = crow[q];
-        const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
-        float vc[4];
+        const f2 c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w};
+        f2 a01 = splat(0.f), a23 = splat(0.f);
 #pragma unroll
-        for (int ei = 0; ei < 4; ++ei) {
-          const int k = 4 * q + ei;
-          float a = 0.f;
-#pragma unroll
-          for (int j = 0; j < PPL; ++j) {
-            if (GEOM) S[j] = fmaf(cv[ei], vout[j][k], S[j]);
-            a = fmaf(fac[j], vout[j][k], a);
+        for (int j = 0; j < PPL; ++j) {
+          if (GEOM) {
+            S2[j] = fma2(c01, vout[j][2 * q], S2[j]);
+            S2[j] = fma2(c23, vout[j][2 * q + 1], S2[j]);
           }
-          vc[ei] = a;
+          const f2 f = splat(fac[j]);
+          a01 = fma2(f, vout[j][2 * q], a01);
+          a23 = fma2(f, vout[j][2 * q + 1], a23);
         }
-        red[q * 68 + lane] = quad_fold_rows(vc[0], vc[1], vc[2], vc[3]);
+        red[q * 68 + lane] = quad_fold_rows(a01[0], a01[1], a23[0], a23[1]);
       }
       if (GEOM) {
+        float S[PPL];
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) S[j] = S2[j][0] + S2[j][1];
         float geo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // x y a b c o |x| |y|
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {

@@ -12,6 +12,13 @@
 
 namespace pr {
 
+// Two-float vector: arithmetic on it compiles to packed-FP32 instructions (v_pk_fma_f32 ...), i.e. one
+// issue slot for two lanes of work.  A wavefront issues at most one VALU instruction every four cycles,
+// so halving the instruction count of the channel loops is worth more than it looks.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;

@@ -29,7 +29,9 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
   const int range_lo = isect_offsets[tile_flat];
   const int range_hi = (tile_flat + 1 < n_regions / Rg::WPT) ? isect_offsets[tile_flat + 1] : n_isects;
 
-  float T[PPL], acc[PPL][CD];
+  constexpr int CH2 = CDP / 2;  // channel pairs
+  float T[PPL];
+  f2 acc[PPL][CH2];
   int last[PPL];
   bool done[PPL], inside[PPL];
   const float px0 = (float)x0 + 0.5f, py0 = (float)y0 + 0.5f;
@@ -41,7 +43,7 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     T[j] = 1.f;
     last[j] = range_lo;
 #pragma unroll
-    for (int k = 0; k < CD; ++k) acc[j][k] = 0.f;
+    for (int k = 0; k < CH2; ++k) acc[j][k] = splat(0.f);
   }
 
   // pixel-centre rectangle of this wave's region, clipped to the image
@@ -95,13 +97,12 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 #pragma unroll
         for (int q = 0; q < CDP / 4; ++q) {
           const float4 c = crow[q];
-          const float cv[4] = {c.x, c.y, c.z, c.w};
+          const f2 c01 = {c.x, c.y}, c23 = {c.z, c.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (4 * q + e < CD) {
-#pragma unroll
-              for (int j = 0; j < PPL; ++j) acc[j][4 * q + e] = fmaf(cv[e], vis[j], acc[j][4 * q + e]);
-            }
+          for (int j = 0; j < PPL; ++j) {
+            const f2 v = splat(vis[j]);
+            acc[j][2 * q] = fma2(c01, v, acc[j][2 * q]);
+            acc[j][2 * q + 1] = fma2(c23, v, acc[j][2 * q + 1]);
           }
         }
       }
@@ -123,22 +124,24 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
       const float *bg = backgrounds + (int64_t)cam * D + ch_off;
 #pragma unroll
       for (int k = 0; k < CD; ++k)
-        if (k < nch) acc[j][k] = fmaf(T[j], bg[k], acc[j][k]);
+        if (k < nch) acc[j][k / 2][k % 2] = fmaf(T[j], bg[k], acc[j][k / 2][k % 2]);
     }
     if (ed_channel >= 0) {  // expected depth: accumulated depth / max(alpha, 1e-10)
       const float inv = 1.f / fmaxf(1.f - T[j], 1e-10f);
 #pragma unroll
       for (int k = 0; k < CD; ++k)
-        if (k + ch_off == ed_channel) acc[j][k] *= inv;
+        if (k + ch_off == ed_channel) acc[j][k / 2][k % 2] *= inv;
     }
     if (((D | ch_off) & 3) == 0) {
 #pragma unroll
       for (int k = 0; k + 3 < CD; k += 4)
-        if (k < nch) *reinterpret_cast<float4 *>(out + k) = make_float4(acc[j][k], acc[j][k + 1], acc[j][k + 2], acc[j][k + 3]);
+        if (k < nch)
+          *reinterpret_cast<float4 *>(out + k) =
+              make_float4(acc[j][k / 2][0], acc[j][k / 2][1], acc[j][k / 2 + 1][0], acc[j][k / 2 + 1][1]);
     } else {
 #pragma unroll
       for (int k = 0; k < CD; ++k)
-        if (k < nch) out[k] = acc[j][k];
+        if (k < nch) out[k] = acc[j][k / 2][k % 2];
     }
     if (ch_off == 0) {
       render_alphas[pix] = 1.f - T[j];
