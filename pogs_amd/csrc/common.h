@@ -94,6 +94,15 @@ __device__ __forceinline__ float quad_reduce(float v0, float v1, float v2, float
   return row_sum_to_lane15(quad_fold_rows(v0, v1, v2, v3));
 }
 
+// Fire-and-forget float atomic add to global memory.  Issued through inline asm on purpose: hipcc's
+// wait-count pass otherwise puts an `s_waitcnt vmcnt(0)` at the head of a loop whose body ends in an atomic,
+// so every iteration would wait out the previous iteration's atomic round trip (1-3 us under load) although
+// nothing ever reads its result.  The instruction still counts in vmcnt in issue order, so the compiler's
+// own (now conservative) waits for later loads stay correct.
+__device__ __forceinline__ void atomic_add_noret(float *addr, float v) {
+  asm volatile("global_atomic_add_f32 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
+}
+
 __device__ __forceinline__ float wave_sum_all(float v) {
   v = wave_sum_to_lane63(v);
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));

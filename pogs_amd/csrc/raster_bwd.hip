@@ -232,14 +232,14 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
           const float v = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w)) +
                           (((p2.x + p2.y) + (p2.z + p2.w)) + ((p3.x + p3.y) + (p3.z + p3.w)));
           if (k < CDP) {
-            if (v_colors && k < nch) atomicAdd(v_colors + (int64_t)gid * D + ch_off + k, v);
+            if (v_colors && k < nch) atomic_add_noret(v_colors + (int64_t)gid * D + ch_off + k, v);
           } else if (GEOM) {
             const int gi = k - CDP;
             const float sc = (k0 == 0) ? gscale
                                        : ((gi == 0 || gi == 1) ? -LN2
                                           : (gi == 2 || gi == 4) ? 0.5f
                                           : (gi == 6 || gi == 7) ? LN2 : 1.f);
-            if (gi < (absgrad ? 8 : 6)) atomicAdd(v_geom + (int64_t)gid * 8 + gi, v * sc);
+            if (gi < (absgrad ? 8 : 6)) atomic_add_noret(v_geom + (int64_t)gid * 8 + gi, v * sc);
           }
         }
       }

@@ -136,6 +136,10 @@ __device__ __forceinline__ unsigned long long stage_batch(
       }
     }
   }
+  // Retire every staging load here.  Without this the compiler leaves some of them pending into the
+  // per-Gaussian loop, and must then put a conservative `s_waitcnt vmcnt(0)` at that loop's head -- which
+  // also waits out the previous iteration's gradient atomics (1-3 us each under load).
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), other counters untouched
   return __builtin_amdgcn_ballot_w64(keep);
 }
 
