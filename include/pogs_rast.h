@@ -103,12 +103,15 @@ int pr_isect_offsets(int64_t n_isects, const int64_t *isect_ids, int C, int tile
  * ed_channel >= 0 names the channel that holds depth and is to be output as EXPECTED depth, i.e. divided by
  * max(alpha, 1e-10) (what gsplat's `rasterization` does after the kernel for render modes ED / RGB+ED);
  * -1 = none.
+ * tile_order (may be NULL) is a permutation of the C*tile_h*tile_w flat tile indices: the order in which
+ * wavefronts pick tiles up.  Results do not depend on it; listing the longest tiles first shortens the tail
+ * of the launch.
  * Out: render_colors[C,H,W,D], render_alphas[C,H,W], last_ids[C,H,W] int32 (one past the index of the
  * last intersection that contributed to the pixel; the tile's first index when none did). */
 int pr_raster_fwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
                   const float *opacities, const float *backgrounds, int width, int height, int tile_size,
-                  int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
-                  int64_t n_isects, int ed_channel, float *render_colors, float *render_alphas,
+                  int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
+                  const int32_t *flatten_ids, int64_t n_isects, int ed_channel, float *render_colors, float *render_alphas,
                   int32_t *last_ids, void *stream);
 /* v_render_colors[C,H,W,D], v_render_alphas[C,H,W]; render_colors (the forward output) is read only when
  * ed_channel >= 0 and may be NULL otherwise.
@@ -119,8 +122,8 @@ int pr_raster_fwd(int C, int N, int D, const float *means2d, const float *conics
  * geom_grad == 0 skips every geometry gradient (v_geom may then be NULL). */
 int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
                   const float *opacities, const float *backgrounds, int width, int height, int tile_size,
-                  int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
-                  int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
+                  int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
+                  const int32_t *flatten_ids, int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
                   const float *render_colors, int ed_channel, const float *v_render_colors,
                   const float *v_render_alphas, int absgrad, int geom_grad, float *v_geom, float *v_colors,
                   void *stream);

@@ -33,9 +33,9 @@ SIGNATURES = {
     "pr_isect_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, c_size_t,
                                    _P]),
     "pr_isect_offsets": (c_int, [c_int64, _P, c_int, c_int, c_int, _P, _P]),
-    "pr_raster_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P,
+    "pr_raster_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                               c_int64, c_int, _P, _P, _P, _P]),
-    "pr_raster_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P,
+    "pr_raster_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                               c_int64, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P]),
 }
 

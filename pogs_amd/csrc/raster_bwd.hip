@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
-    const int32_t *__restrict__ flatten_ids, int n_isects, const float *__restrict__ render_alphas,
+    const int32_t *__restrict__ tile_order, const int32_t *__restrict__ flatten_ids, int n_isects, const float *__restrict__ render_alphas,
     const int32_t *__restrict__ last_ids, const float *__restrict__ render_colors, int ed_channel,
     const float *__restrict__ v_render_colors, const float *__restrict__ v_render_alphas, int absgrad,
     float *__restrict__ v_geom, float *__restrict__ v_colors) {
@@ -35,12 +35,15 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
   constexpr int NV = CDP + (GEOM ? 8 : 0);    // values reduced per Gaussian
   __shared__ WaveLds<CD> lds[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  // Without an explicit order, blocks that share an XCD take a contiguous range of tiles (neighbouring
+  // tiles share Gaussians -> one L2).  With one, slot s processes tile tile_order[s]: the caller lists the
+  // tiles heaviest first so the last waves of the launch are the cheapest ones.
+  const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   const int region = (int)bid * 4 + wave;
   if (region >= n_regions) return;
   WaveLds<CD> &L = lds[wave];
 
-  const int tile_flat = region / Rg::WPT, sub = region % Rg::WPT;
+  const int tile_flat = tile_order ? tile_order[region / Rg::WPT] : region / Rg::WPT, sub = region % Rg::WPT;
   const int n_tiles = tile_w * tile_h;
   const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
   const int ty = tile / tile_w, tx = tile % tile_w;
@@ -250,7 +253,8 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
 template <int TS, int PPL, int CD, bool GEOM>
 static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const float *colors,
                       const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
-                      const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects,
+                      const int32_t *isect_offsets, const int32_t *tile_order, const int32_t *flatten_ids,
+                      int64_t n_isects,
                       const float *render_alphas, const int32_t *last_ids, const float *render_colors,
                       int ed_channel, const float *v_render_colors, const float *v_render_alphas, int absgrad,
                       float *v_geom, float *v_colors, hipStream_t stream) {
@@ -258,7 +262,7 @@ static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, con
   const unsigned grid = (unsigned)((n_regions + 3) / 4);
   hipLaunchKernelGGL((raster_bwd_kernel<TS, PPL, CD, GEOM>), dim3(grid), dim3(256), 0, stream, (int)n_regions, N, D,
                      ch_off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h,
-                     isect_offsets, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel,
+                     isect_offsets, tile_order, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel,
                      v_render_colors, v_render_alphas, absgrad, v_geom, v_colors);
   return check_launch("raster_bwd_kernel");
 }
@@ -278,7 +282,7 @@ extern "C" int pr_max_channels(void) { return 100; }
 
 #define BWD_ARGS                                                                                                     \
   C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,       \
-      flatten_ids, n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas,   \
+      tile_order, flatten_ids, n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas,   \
       absgrad, v_geom, v_colors, (hipStream_t)stream
 #define BWD_CASE(TS, PPL, CDV)                                      \
   case CDV:                                                         \
@@ -288,8 +292,8 @@ extern "C" int pr_max_channels(void) { return 100; }
 
 extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
                              const float *opacities, const float *backgrounds, int width, int height, int tile_size,
-                             int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
-                             int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
+                             int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
+                             const int32_t *flatten_ids, int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
                              const float *render_colors, int ed_channel, const float *v_render_colors, const float *v_render_alphas, int absgrad, int geom_grad,
                              float *v_geom, float *v_colors, void *stream) {
   if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)

@@ -8,19 +8,22 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
-    const int32_t *__restrict__ flatten_ids, int n_isects, int ed_channel, float *__restrict__ render_colors,
+    const int32_t *__restrict__ tile_order, const int32_t *__restrict__ flatten_ids, int n_isects, int ed_channel, float *__restrict__ render_colors,
     float *__restrict__ render_alphas, int32_t *__restrict__ last_ids) {
   using Rg = Region<TS, PPL>;
   constexpr int ROW = color_row(CD);
   constexpr int CDP = round4(CD);
   __shared__ WaveLds<CD> lds[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+  // Without an explicit order, blocks that share an XCD take a contiguous range of tiles (neighbouring
+  // tiles share Gaussians -> one L2).  With one, slot s processes tile tile_order[s]: the caller lists the
+  // tiles heaviest first so the last waves of the launch are the cheapest ones.
+  const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   const int region = (int)bid * 4 + wave;
   if (region >= n_regions) return;
   WaveLds<CD> &L = lds[wave];
 
-  const int tile_flat = region / Rg::WPT, sub = region % Rg::WPT;
+  const int tile_flat = tile_order ? tile_order[region / Rg::WPT] : region / Rg::WPT, sub = region % Rg::WPT;
   const int n_tiles = tile_w * tile_h;
   const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
   const int ty = tile / tile_w, tx = tile % tile_w;
@@ -153,13 +156,14 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 template <int TS, int PPL, int CD>
 static int launch_fwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const float *colors,
                       const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
-                      const int32_t *isect_offsets, const int32_t *flatten_ids, int64_t n_isects, int ed_channel,
+                      const int32_t *isect_offsets, const int32_t *tile_order, const int32_t *flatten_ids,
+                      int64_t n_isects, int ed_channel,
                       float *render_colors, float *render_alphas, int32_t *last_ids, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
   const unsigned grid = (unsigned)((n_regions + 3) / 4);
   hipLaunchKernelGGL((raster_fwd_kernel<TS, PPL, CD>), dim3(grid), dim3(256), 0, stream, (int)n_regions, N, D, ch_off,
                      means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
-                     flatten_ids, (int)n_isects, ed_channel, render_colors, render_alphas, last_ids);
+                     tile_order, flatten_ids, (int)n_isects, ed_channel, render_colors, render_alphas, last_ids);
   return check_launch("raster_fwd_kernel");
 }
 
@@ -180,14 +184,15 @@ using namespace pr;
 #define FWD_CASE(TS, PPL, CDV)                                                                                        \
   case CDV:                                                                                                           \
     rc = launch_fwd<TS, PPL, CDV>(C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height,       \
-                                  tile_w, tile_h, isect_offsets, flatten_ids, n_isects, ed_channel, render_colors,    \
+                                  tile_w, tile_h, isect_offsets, tile_order, flatten_ids, n_isects, ed_channel,       \
+                                  render_colors,                                                                      \
                                   render_alphas, last_ids, (hipStream_t)stream);                                      \
     break;
 
 extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
                              const float *opacities, const float *backgrounds, int width, int height, int tile_size,
-                             int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *flatten_ids,
-                             int64_t n_isects, int ed_channel, float *render_colors, float *render_alphas,
+                             int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
+                             const int32_t *flatten_ids, int64_t n_isects, int ed_channel, float *render_colors, float *render_alphas,
                              int32_t *last_ids, void *stream) {
   if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)
     return PR_EINVAL;

@@ -227,6 +227,16 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
     return offsets
 
 
+def _tile_order(isect_offsets: Tensor, n_isects: int) -> Optional[Tensor]:
+    """Flat tile indices sorted by list length, longest first: wavefronts pick the heavy tiles up first so
+    that the launch does not end on a few long ones (results do not depend on the order)."""
+    o = isect_offsets.flatten()
+    if o.numel() < 2048:  # fewer tiles than wave slots: nothing to balance
+        return None
+    ends = torch.cat([o[1:], o.new_tensor([n_isects])])
+    return torch.argsort(ends - o, descending=True).to(torch.int32)
+
+
 class _Rasterize(torch.autograd.Function):
     """Tile compositing; stands in for gsplat ``rasterize_to_pixels``."""
 
@@ -243,13 +253,14 @@ class _Rasterize(torch.autograd.Function):
         render_colors = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
         render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
+        tile_order = _tile_order(isect_offsets, flatten_ids.numel())
         with torch.cuda.device(dev):
             _call("pr_raster_fwd", C, N, D, _ptr(means2d_c), _ptr(conics), _ptr(colors), _ptr(opacities),
                                          _ptr(backgrounds), width, height, tile_size, tw, th, _ptr(isect_offsets),
-                                         _ptr(flatten_ids), flatten_ids.numel(), ed_channel, _ptr(render_colors),
+                                         _ptr(tile_order), _ptr(flatten_ids), flatten_ids.numel(), ed_channel, _ptr(render_colors),
                                          _ptr(render_alphas), _ptr(last_ids), _stream())
         ctx.save_for_backward(means2d_c, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids,
-                              render_alphas, last_ids, render_colors if ed_channel >= 0 else None)
+                              render_alphas, last_ids, render_colors if ed_channel >= 0 else None, tile_order)
         ctx.args = (width, height, tile_size, absgrad, ed_channel)
         ctx.means2d_obj = means2d  # the object callers hold in meta["means2d"]; receives .absgrad
         return render_colors, render_alphas
@@ -258,7 +269,7 @@ class _Rasterize(torch.autograd.Function):
     def backward(ctx, v_render_colors, v_render_alphas):
         lib = _lib.load()
         (means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, render_alphas,
-         last_ids, render_colors) = ctx.saved_tensors
+         last_ids, render_colors, tile_order) = ctx.saved_tensors
         width, height, tile_size, absgrad, ed_channel = ctx.args
         C, N, D = colors.shape
         dev = means2d.device
@@ -276,8 +287,8 @@ class _Rasterize(torch.autograd.Function):
             with torch.cuda.device(dev):
                 _call("pr_raster_bwd", C, N, D, _ptr(means2d), _ptr(conics), _ptr(colors), _ptr(opacities),
                                              _ptr(backgrounds), width, height, tile_size, tw, th,
-                                             _ptr(isect_offsets), _ptr(flatten_ids), flatten_ids.numel(),
-                                             _ptr(render_alphas), _ptr(last_ids), _ptr(render_colors), ed_channel,
+                                             _ptr(isect_offsets), _ptr(tile_order), _ptr(flatten_ids),
+                                             flatten_ids.numel(), _ptr(render_alphas), _ptr(last_ids), _ptr(render_colors), ed_channel,
                                              _ptr(v_render_colors), _ptr(v_render_alphas), int(absgrad),
                                              int(geom), _ptr(v_geom), _ptr(v_colors), _stream())
         v_means2d = v_conics = v_opacities = None
