@@ -143,7 +143,9 @@ def main():
     params = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in params.items()}
     viewmat = sc.viewmats[view:view + 1].to(dev).contiguous()
     K = sc.Ks[view:view + 1].to(dev).contiguous()
-    grads = FlatGrads(params.values())
+    # Multi-GPU: every .grad aliases one flat buffer that is mean-all-reduced each step.  Single GPU: plain
+    # zero_grad(set_to_none=True) semantics, as the reference's trainer does between iterations.
+    grads = FlatGrads(params.values()) if world > 1 else None
     D = 3 + F + 1
     g = torch.Generator().manual_seed(100 + rank)
     v_colors = torch.randn(1, H, W, D, generator=g).to(dev)
@@ -151,7 +153,11 @@ def main():
     info = {}
 
     def step():
-        grads.zero_()
+        if grads is not None:
+            grads.zero_()
+        else:
+            for p in params.values():
+                p.grad = None
         scales = torch.exp(params["log_scales"])
         opac = torch.sigmoid(params["opacity_logits"])
         common = dict(means=params["means"], quats=params["quats"], scales=scales, opacities=opac, viewmats=viewmat,
@@ -226,7 +232,7 @@ def main():
                                  N, W, H, F, ts, ", fused single call" if not args.two_call else ", two calls")),
                 "gaussians": N, "width": W, "height": H, "channels": D, "n_isects": I,
                 "parallelism": "camera-sharded dp%d, flat-gradient mean all-reduce (%.0f MB)" % (
-                    world, grads.nbytes() / 1e6) if world > 1 else "single GPU",
+                    world, (grads.nbytes() if grads is not None else 0) / 1e6) if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
