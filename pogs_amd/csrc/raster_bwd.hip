@@ -15,6 +15,8 @@
 // values, every lane of row r holding a 4-lane partial of value 4q+slot(r).  Each quad's register goes to
 // the wave's LDS slice as one unpredicated store; lane v then reads back the 16 partials of value v as
 // four 16-byte loads, adds them, and issues the atomic -- contiguous addresses per Gaussian.
+#include <stdlib.h>
+
 #include "raster_common.h"
 
 namespace pr {
@@ -267,11 +269,41 @@ static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, con
   return check_launch("raster_bwd_kernel");
 }
 
-static const int kChunks[] = {4, 8, 16, 24, 32, 36, 48, 64, 100};
+static const int kChunks[] = {4, 8, 16, 24, 32, 36, 48, 64, 72, 100};
 static int pick_chunk(int want) {
   for (int c : kChunks)
     if (c >= want) return c;
   return -1;
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+struct BwdPlan {
+  int ppl, per;
+};
+
+// Geometry gradients need the dot product over ALL channels in one pass; colour-only gradients can be
+// chunked freely (narrow chunks keep 4 pixels per lane).  POGS_RAST_BWD_PPL overrides (tuning aid).
+static BwdPlan plan_bwd(int D, int geom_grad, int tile_size, int64_t n_tiles_total) {
+  BwdPlan p;
+  p.per = D;
+  if (!geom_grad && D > 36) {
+    const int n_chunks = (D + 35) / 36;
+    p.per = ((D + n_chunks - 1) / n_chunks + 3) & ~3;
+  }
+  if (tile_size == 8) {
+    p.ppl = 1;
+    return p;
+  }
+  const int cd = pick_chunk(p.per);
+  p.ppl = cd <= 36 ? 4 : cd <= 72 ? 2 : 1;
+  while (p.ppl > 1 && n_tiles_total * (4 / p.ppl) < 3072) p.ppl >>= 1;
+  const int forced = env_int("POGS_RAST_BWD_PPL", 0);
+  if (forced == 1 || (forced == 2 && cd <= 72) || (forced == 4 && cd <= 36)) p.ppl = forced;
+  return p;
 }
 
 }  // namespace pr
@@ -282,8 +314,8 @@ extern "C" int pr_max_channels(void) { return 100; }
 
 #define BWD_ARGS                                                                                                     \
   C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,       \
-      tile_order, flatten_ids, n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas,   \
-      absgrad, v_geom, v_colors, (hipStream_t)stream
+      tile_order, flatten_ids, n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors,        \
+      v_render_alphas, absgrad, v_geom, v_colors, (hipStream_t)stream
 #define BWD_CASE(TS, PPL, CDV)                                      \
   case CDV:                                                         \
     rc = geom_grad ? launch_bwd<TS, PPL, CDV, true>(BWD_ARGS)       \
@@ -293,8 +325,9 @@ extern "C" int pr_max_channels(void) { return 100; }
 extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
                              const float *opacities, const float *backgrounds, int width, int height, int tile_size,
                              int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
-                             const int32_t *flatten_ids, int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
-                             const float *render_colors, int ed_channel, const float *v_render_colors, const float *v_render_alphas, int absgrad, int geom_grad,
+                             const int32_t *flatten_ids, int64_t n_isects, const float *render_alphas,
+                             const int32_t *last_ids, const float *render_colors, int ed_channel,
+                             const float *v_render_colors, const float *v_render_alphas, int absgrad, int geom_grad,
                              float *v_geom, float *v_colors, void *stream) {
   if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)
     return PR_EINVAL;
@@ -309,25 +342,29 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
   if (ed_channel >= D || (ed_channel >= 0 && !render_colors)) return PR_EINVAL;
   if (!geom_grad && !v_colors) return PR_OK;
   if ((int64_t)C * tile_w * tile_h * 4 > 2147483647ll) return PR_EUNSUPPORTED;
-  // Geometry gradients need the dot product over ALL channels in one pass; colour-only gradients can
-  // be chunked freely, and narrow chunks keep 4 pixels per lane.
-  int per = D;
-  if (!geom_grad && D > 36) {
-    const int n_chunks = (D + 35) / 36;
-    per = ((D + n_chunks - 1) / n_chunks + 3) & ~3;
-  }
-  for (int off = 0; off < D; off += per) {
-    const int cd = pick_chunk(min(per, D - off));
+  const BwdPlan plan = plan_bwd(D, geom_grad, tile_size, (int64_t)C * tile_w * tile_h);
+  for (int off = 0; off < D; off += plan.per) {
+    const int cd = pick_chunk(min(plan.per, D - off));
     int rc = PR_EUNSUPPORTED;
-    if (tile_size == 16) {
+    if (tile_size == 8) {
+      switch (cd) {
+        BWD_CASE(8, 1, 4) BWD_CASE(8, 1, 8) BWD_CASE(8, 1, 16) BWD_CASE(8, 1, 24) BWD_CASE(8, 1, 32)
+        BWD_CASE(8, 1, 36) BWD_CASE(8, 1, 48) BWD_CASE(8, 1, 64) BWD_CASE(8, 1, 72) BWD_CASE(8, 1, 100)
+      }
+    } else if (plan.ppl == 4) {
       switch (cd) {
         BWD_CASE(16, 4, 4) BWD_CASE(16, 4, 8) BWD_CASE(16, 4, 16) BWD_CASE(16, 4, 24) BWD_CASE(16, 4, 32)
-        BWD_CASE(16, 4, 36) BWD_CASE(16, 2, 48) BWD_CASE(16, 2, 64) BWD_CASE(16, 1, 100)
+        BWD_CASE(16, 4, 36)
+      }
+    } else if (plan.ppl == 2) {
+      switch (cd) {
+        BWD_CASE(16, 2, 4) BWD_CASE(16, 2, 8) BWD_CASE(16, 2, 16) BWD_CASE(16, 2, 24) BWD_CASE(16, 2, 32)
+        BWD_CASE(16, 2, 36) BWD_CASE(16, 2, 48) BWD_CASE(16, 2, 64) BWD_CASE(16, 2, 72)
       }
     } else {
       switch (cd) {
-        BWD_CASE(8, 1, 4) BWD_CASE(8, 1, 8) BWD_CASE(8, 1, 16) BWD_CASE(8, 1, 24) BWD_CASE(8, 1, 32)
-        BWD_CASE(8, 1, 36) BWD_CASE(8, 1, 48) BWD_CASE(8, 1, 64) BWD_CASE(8, 1, 100)
+        BWD_CASE(16, 1, 4) BWD_CASE(16, 1, 8) BWD_CASE(16, 1, 16) BWD_CASE(16, 1, 24) BWD_CASE(16, 1, 32)
+        BWD_CASE(16, 1, 36) BWD_CASE(16, 1, 48) BWD_CASE(16, 1, 64) BWD_CASE(16, 1, 72) BWD_CASE(16, 1, 100)
       }
     }
     if (rc) return rc;

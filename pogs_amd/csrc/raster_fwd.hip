@@ -1,4 +1,6 @@
 // Forward compositing kernel for gfx950: per-tile front-to-back alpha blending.
+#include <stdlib.h>
+
 #include "raster_common.h"
 
 namespace pr {
@@ -167,33 +169,66 @@ static int launch_fwd(int C, int N, int D, int ch_off, const float *means2d, con
   return check_launch("raster_fwd_kernel");
 }
 
-// Channel-chunk widths with a compiled kernel.
-static const int kChunks[] = {4, 8, 16, 24, 32, 36, 40, 48};
-constexpr int kMaxChunk = 48;
+// Compiled (pixels-per-lane, channel-chunk) combinations for 16x16 tiles; 8x8 tiles always use one
+// wavefront per tile (1 pixel per lane).  More pixels per lane amortise the per-Gaussian overhead better
+// but need PPL * CD accumulator registers and give fewer wavefronts, so narrow renders of small images
+// drop to fewer pixels per lane to keep the chip filled.
+static const int kChunks[] = {4, 8, 16, 24, 32, 36, 48, 64, 72, 100};
 
 static int pick_chunk(int want) {
   for (int c : kChunks)
     if (c >= want) return c;
-  return kMaxChunk;
+  return -1;
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+struct FwdPlan {
+  int ppl, per;
+};
+
+// D channels -> chunk width and pixels per lane.  POGS_RAST_FWD_PPL / POGS_RAST_FWD_CHUNK override (tuning aid).
+static FwdPlan plan_fwd(int D, int tile_size, int64_t n_tiles_total) {
+  FwdPlan p;
+  // Large images have tiles to spare: channel chunks of <= 48 keep 4 pixels per lane (alpha is recomputed
+  // per chunk, which is cheaper than losing the per-Gaussian amortisation).  Small images take all channels
+  // in one pass with fewer pixels per lane, which also doubles or quadruples the number of wavefronts.
+  const bool many_tiles = tile_size == 16 && n_tiles_total >= 3072;
+  int max_chunk = env_int("POGS_RAST_FWD_CHUNK", many_tiles ? 48 : 100);
+  const int n_chunks = (D + max_chunk - 1) / max_chunk;
+  p.per = ((D + n_chunks - 1) / n_chunks + 3) & ~3;
+  if (tile_size == 8) {
+    p.ppl = 1;
+    return p;
+  }
+  const int cd = pick_chunk(p.per);
+  p.ppl = cd <= 48 ? 4 : cd <= 72 ? 2 : 1;
+  while (p.ppl > 1 && n_tiles_total * (4 / p.ppl) < 3072) p.ppl >>= 1;
+  const int forced = env_int("POGS_RAST_FWD_PPL", 0);
+  if (forced == 1 || (forced == 2 && cd <= 72) || (forced == 4 && cd <= 48)) p.ppl = forced;
+  return p;
 }
 
 }  // namespace pr
 
 using namespace pr;
 
-#define FWD_CASE(TS, PPL, CDV)                                                                                        \
-  case CDV:                                                                                                           \
-    rc = launch_fwd<TS, PPL, CDV>(C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height,       \
-                                  tile_w, tile_h, isect_offsets, tile_order, flatten_ids, n_isects, ed_channel,       \
-                                  render_colors,                                                                      \
-                                  render_alphas, last_ids, (hipStream_t)stream);                                      \
+#define FWD_ARGS                                                                                                    \
+  C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,      \
+      tile_order, flatten_ids, n_isects, ed_channel, render_colors, render_alphas, last_ids, (hipStream_t)stream
+#define FWD_CASE(TS, PPL, CDV) \
+  case CDV:                    \
+    rc = launch_fwd<TS, PPL, CDV>(FWD_ARGS); \
     break;
 
 extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
                              const float *opacities, const float *backgrounds, int width, int height, int tile_size,
                              int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
-                             const int32_t *flatten_ids, int64_t n_isects, int ed_channel, float *render_colors, float *render_alphas,
-                             int32_t *last_ids, void *stream) {
+                             const int32_t *flatten_ids, int64_t n_isects, int ed_channel, float *render_colors,
+                             float *render_alphas, int32_t *last_ids, void *stream) {
   if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)
     return PR_EINVAL;
   if (tile_size != 16 && tile_size != 8) return PR_EUNSUPPORTED;
@@ -204,20 +239,29 @@ extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const fl
   if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return PR_EINVAL;
   if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return PR_EINVAL;
   if ((int64_t)C * tile_w * tile_h * 4 > 2147483647ll) return PR_EUNSUPPORTED;
-  const int n_chunks = (D + kMaxChunk - 1) / kMaxChunk;
-  const int per = ((D + n_chunks - 1) / n_chunks + 3) & ~3;
-  for (int off = 0; off < D; off += per) {
-    const int cd = pick_chunk(min(per, D - off));
+  const FwdPlan plan = plan_fwd(D, tile_size, (int64_t)C * tile_w * tile_h);
+  for (int off = 0; off < D; off += plan.per) {
+    const int cd = pick_chunk(min(plan.per, D - off));
     int rc = PR_EUNSUPPORTED;
-    if (tile_size == 16) {
+    if (tile_size == 8) {
+      switch (cd) {
+        FWD_CASE(8, 1, 4) FWD_CASE(8, 1, 8) FWD_CASE(8, 1, 16) FWD_CASE(8, 1, 24) FWD_CASE(8, 1, 32)
+        FWD_CASE(8, 1, 36) FWD_CASE(8, 1, 48) FWD_CASE(8, 1, 64) FWD_CASE(8, 1, 72) FWD_CASE(8, 1, 100)
+      }
+    } else if (plan.ppl == 4) {
       switch (cd) {
         FWD_CASE(16, 4, 4) FWD_CASE(16, 4, 8) FWD_CASE(16, 4, 16) FWD_CASE(16, 4, 24) FWD_CASE(16, 4, 32)
-        FWD_CASE(16, 4, 36) FWD_CASE(16, 4, 40) FWD_CASE(16, 4, 48)
+        FWD_CASE(16, 4, 36) FWD_CASE(16, 4, 48)
+      }
+    } else if (plan.ppl == 2) {
+      switch (cd) {
+        FWD_CASE(16, 2, 4) FWD_CASE(16, 2, 8) FWD_CASE(16, 2, 16) FWD_CASE(16, 2, 24) FWD_CASE(16, 2, 32)
+        FWD_CASE(16, 2, 36) FWD_CASE(16, 2, 48) FWD_CASE(16, 2, 64) FWD_CASE(16, 2, 72)
       }
     } else {
       switch (cd) {
-        FWD_CASE(8, 1, 4) FWD_CASE(8, 1, 8) FWD_CASE(8, 1, 16) FWD_CASE(8, 1, 24) FWD_CASE(8, 1, 32)
-        FWD_CASE(8, 1, 36) FWD_CASE(8, 1, 40) FWD_CASE(8, 1, 48)
+        FWD_CASE(16, 1, 4) FWD_CASE(16, 1, 8) FWD_CASE(16, 1, 16) FWD_CASE(16, 1, 24) FWD_CASE(16, 1, 32)
+        FWD_CASE(16, 1, 36) FWD_CASE(16, 1, 48) FWD_CASE(16, 1, 64) FWD_CASE(16, 1, 72) FWD_CASE(16, 1, 100)
       }
     }
     if (rc) return rc;
