@@ -53,10 +53,14 @@ def test_argument_validation_needs_no_gpu():
     assert lib.pr_project_fwd(1, 4, None, None, None, None, None, 8, 8, 0.3, 0.01, 1e10, 0.0,
                               None, None, None, None, None, None) == -1          # null pointers
     assert lib.pr_sh_fwd(1, 4, 16, 4, None, None, None, None, 1, None, 3, None) == -2   # degree 4 unsupported
-    assert lib.pr_raster_fwd(1, 4, 3, None, None, None, None, None, 64, 64, 12, 6, 6, None, None, 0,
+    assert lib.pr_raster_fwd(1, 4, 3, None, None, None, None, None, 64, 64, 12, 6, 6, None, None, None, 0, -1,
                              None, None, None, None) == -2                        # tile size 12 unsupported
-    assert lib.pr_raster_fwd(1, 4, 3, None, None, None, None, None, 64, 64, 16, 2, 2, None, None, 0,
+    assert lib.pr_raster_fwd(1, 4, 3, None, None, None, None, None, 64, 64, 16, 2, 2, None, None, None, 0, -1,
                              None, None, None, None) == -1                        # tile grid does not cover the image
+    assert lib.pr_raster_fwd(1, 4, 3, None, None, None, None, None, 64, 64, 16, 4, 4, None, None, None, 0, 3,
+                             None, None, None, None) == -1                        # depth channel index out of range
+    assert lib.pr_raster_fwd(1, 4, 101, None, None, None, None, None, 64, 64, 16, 4, 4, None, None, None, 0, -1,
+                             None, None, None, None) == -2                        # more channels than any kernel takes
 
 
 def test_rasterization_fails_loudly_without_gpu_tensors():
@@ -79,3 +83,16 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "oracle/" not in text, f
+
+
+def test_gsplat_import_shim_resolves_to_this_package():
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from gsplat.rendering import rasterization; import pogs_amd.rendering as r;"
+            "from gsplat.cuda._torch_impl import _quat_to_rotmat; import torch;"
+            "assert rasterization is r.rasterization;"
+            "assert torch.allclose(_quat_to_rotmat(torch.tensor([1.,0,0,0])), torch.eye(3))"
+            % (os.path.join(ROOT, "drop_in"), ROOT))
+    subprocess.run([sys.executable, "-c", code], check=True)
