@@ -128,6 +128,23 @@ int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics
                   const float *v_render_alphas, int absgrad, int geom_grad, float *v_geom, float *v_colors,
                   void *stream);
 
+/* ---- rigid-group transform of the Gaussian model (the tracker's per-iteration pose update) ----
+ * Replaces the Warp kernel apply_to_model (pogs/tracking/utils.py:53-93, launched at
+ * pogs/tracking/rigid_group_optimizer.py:466-477) and its wp.Tape backward (:413-430).
+ * init_p2ws[G,7], p_deltas[G,7]: poses as (x y z qw qx qy qz); labels[N] int32 in [0,G) (a label outside
+ * that range leaves the Gaussian where it is and contributes no gradient); means[N,3]; quats[N,4] (w x y z).
+ *   (means_out[n], quats_out[n]) = p2w[g] * delta[g] * inverse(p2w[g]) * (means[n], quats[n])
+ * with Warp's transform algebra (quaternions are taken as given, not renormalised). */
+int pr_rigid_fwd(int64_t N, int G, const float *init_p2ws, const float *p_deltas, const int32_t *labels,
+                 const float *means, const float *quats, float *means_out, float *quats_out, void *stream);
+/* Adjoint with respect to p_deltas only (the tracker's one trainable tensor). v_means_out[N,3];
+ * v_quats_out[N,4] in (w x y z) order, or NULL when the cotangent of quats_out is zero -- the reference
+ * allocates quats_out with requires_grad=False (rigid_group_optimizer.py:460-462), so its tape only ever
+ * sees the means' cotangent. v_p_deltas[G,7] is zero-filled by the caller and accumulated into. */
+int pr_rigid_bwd(int64_t N, int G, const float *init_p2ws, const float *p_deltas, const int32_t *labels,
+                 const float *means, const float *quats, const float *v_means_out, const float *v_quats_out,
+                 float *v_p_deltas, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,8 @@ SIGNATURES = {
                               c_int64, c_int, _P, _P, _P, _P]),
     "pr_raster_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                               c_int64, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P]),
+    "pr_rigid_fwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pr_rigid_bwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None
