@@ -2,13 +2,14 @@
 stress shape.  Prints one JSON object per config.  The headline (cfg2) lives in bench.py."""
 import json
 import math
+import os
 import sys
 import time
 
 import torch
 
 sys.path.insert(0, ".")
-from pogs_amd import rendering  # noqa: E402
+from pogs_amd import rendering, tracking  # noqa: E402
 from pogs_amd.scenes import make_scene  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -66,7 +67,8 @@ def tracking_loop(n=200_000, w=640, h=360, groups=4, iters=50, frames=3):
     """cfg3: per frame `iters` pose-optimisation iterations; each renders RGB+ED (SH degree 3, tile 8) and a
     64-channel feature image (tile 16, geometry other than the means detached) of the object's Gaussians
     after a per-group rigid transform, back-propagates an L2 loss to the [G,7] pose deltas, Adam step.
-    The rigid transform (the reference's Warp kernel, pogs/tracking/utils.py:53-93) is plain torch here."""
+    The rigid transform (the reference's Warp kernel, pogs/tracking/utils.py:53-93) is pr_rigid_fwd/bwd; set
+    POGS_BENCH_TORCH_RIGID=1 to time the plain-torch formulation (one-hot GEMM gather) instead."""
     sc = make_scene(n, w, h, n_features=64, seed=0)
     means, quats = sc.means.to(dev), torch.nn.functional.normalize(sc.quats, dim=-1).to(dev)
     scales, opac = sc.log_scales.exp().to(dev), torch.sigmoid(sc.opacity_logits).to(dev)
@@ -76,6 +78,10 @@ def tracking_loop(n=200_000, w=640, h=360, groups=4, iters=50, frames=3):
     onehot = torch.nn.functional.one_hot(labels, groups).float()  # gather as a GEMM: its backward is a GEMM too
     deltas = torch.zeros(groups, 7, device=dev)
     deltas[:, 3] = 1.0
+    p2w = deltas.clone()
+    p2w[:, :3] = torch.randn(groups, 3, device=dev) * 0.3
+    labels32 = labels.int()
+    torch_rigid = os.environ.get("POGS_BENCH_TORCH_RIGID") == "1"
     deltas.requires_grad_(True)
     opt = torch.optim.Adam([deltas], lr=1e-3)
     with torch.no_grad():
@@ -85,10 +91,13 @@ def tracking_loop(n=200_000, w=640, h=360, groups=4, iters=50, frames=3):
 
     def iteration():
         opt.zero_grad(set_to_none=True)
-        per = onehot @ torch.cat([deltas[:, :3], torch.nn.functional.normalize(deltas[:, 3:], dim=-1)], -1)
-        dq = per[:, 3:]
-        m = quat_rotate(dq, means) + per[:, :3]
-        q = quat_mul(dq, quats)
+        if torch_rigid:
+            per = onehot @ torch.cat([deltas[:, :3], torch.nn.functional.normalize(deltas[:, 3:], dim=-1)], -1)
+            dq = per[:, 3:]
+            m = quat_rotate(dq, means) + per[:, :3]
+            q = quat_mul(dq, quats)
+        else:
+            m, q = tracking.apply_to_model(p2w, deltas, labels32, means, quats)
         rgb, _, _ = rendering.rasterization(m, q, scales, opac, sh, vm, K, w, h, sh_degree=3, render_mode="RGB+ED",
                                             packed=False, tile_size=8)
         f, _, _ = rendering.rasterization(m, q.detach(), scales, opac, feats, vm, K, w, h, packed=False)
@@ -101,7 +110,8 @@ def tracking_loop(n=200_000, w=640, h=360, groups=4, iters=50, frames=3):
             iteration()
 
     ms = timed(frame, frames, 1)
-    return {"gaussians": n, "size": [w, h], "iters_per_frame": iters, "ms_per_frame": ms, "ms_per_iter": ms / iters}
+    return {"gaussians": n, "size": [w, h], "iters_per_frame": iters, "ms_per_frame": ms, "ms_per_iter": ms / iters,
+            "rigid": "torch" if torch_rigid else "pr_rigid"}
 
 
 if __name__ == "__main__":
