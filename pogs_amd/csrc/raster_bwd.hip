@@ -20,9 +20,12 @@
 #include "raster_common.h"
 
 namespace pr {
+#ifdef PR_DIAG
+__device__ unsigned long long g_diag[8];
+#endif
 
 template <int TS, int PPL, int CD, bool GEOM>
-__global__ void __launch_bounds__(256) raster_bwd_kernel(
+__global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
@@ -35,13 +38,15 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
   constexpr int CDP = round4(CD);
   constexpr int NQ = CDP / 4;                 // colour quads
   constexpr int NV = CDP + (GEOM ? 8 : 0);    // values reduced per Gaussian
-  __shared__ WaveLds<CD> lds[4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // colour quads handled per pass over the pixel slots (one wave-uniform branch per slot and pass)
+  constexpr int QG = NQ % 3 == 0 ? 3 : NQ % 4 == 0 ? 4 : NQ % 5 == 0 ? 5 : NQ % 2 == 0 ? 2 : 1;
+  __shared__ WaveLds<CD> lds[WPB];
+  const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // Without an explicit order, blocks that share an XCD take a contiguous range of tiles (neighbouring
   // tiles share Gaussians -> one L2).  With one, slot s processes tile tile_order[s]: the caller lists the
   // tiles heaviest first so the last waves of the launch are the cheapest ones.
   const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-  const int region = (int)bid * 4 + wave;
+  const int region = (int)bid * WPB + wave;
   if (region >= n_regions) return;
   WaveLds<CD> &L = lds[wave];
 
@@ -49,8 +54,8 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
   const int n_tiles = tile_w * tile_h;
   const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
   const int ty = tile / tile_w, tx = tile % tile_w;
-  const int x0 = tx * TS + (lane % Rg::LX) * Rg::BW;
-  const int y0 = ty * TS + sub * Rg::RH + (lane / Rg::LX) * Rg::BH;
+  const int x0 = tx * TS + (lane % Rg::LX) * Rg::PX;
+  const int y0 = ty * TS + sub * Rg::RH + (lane / Rg::LX) * Rg::PY;
   const int range_lo = isect_offsets[tile_flat];
   const int nch = min(CD, D - ch_off);
 
@@ -62,7 +67,7 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
   int max_last = range_lo;
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
-    const int x = x0 + (j % Rg::BW), y = y0 + (j / Rg::BW);
+    const int x = x0 + (j % Rg::BW) * Rg::SX, y = y0 + (j / Rg::BW) * Rg::SY;
     const bool inside = x < width && y < height;
     const int64_t pix = ((int64_t)cam * height + y) * width + x;
     T[j] = 1.f;
@@ -145,17 +150,18 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
       float dx[Rg::BW], dy[Rg::BH], adx2[Rg::BW], cdy2[Rg::BH], bdx[Rg::BW];
 #pragma unroll
       for (int i = 0; i < Rg::BW; ++i) {
-        dx[i] = g.x - (px0 + (float)i);
+        dx[i] = g.x - (px0 + (float)(i * Rg::SX));
         adx2[i] = g.w * dx[i] * dx[i];
         bdx[i] = h.x * dx[i];
       }
 #pragma unroll
       for (int i = 0; i < Rg::BH; ++i) {
-        dy[i] = g.y - (py0 + (float)i);
+        dy[i] = g.y - (py0 + (float)(i * Rg::SY));
         cdy2[i] = h.y * dy[i] * dy[i];
       }
       float e[PPL], alpha[PPL];
-      bool active[PPL], any = false;
+      bool active[PPL];
+      unsigned long long slot[PPL], any = 0ull;  // per pixel slot: the lanes with an active pixel
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
         const int jx = j % Rg::BW, jy = j / Rg::BW;
@@ -163,16 +169,38 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
         e[j] = __builtin_amdgcn_exp2f(power);
         alpha[j] = fminf(ALPHA_MAX, g.z * e[j]);
         active[j] = (power <= 0.f) && (alpha[j] >= ALPHA_MIN) && (idx < last[j]);
-        any = any || active[j];
+        slot[j] = __builtin_amdgcn_ballot_w64(active[j]);
+        any |= slot[j];
       }
-      if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
+      if (any == 0ull) continue;
+#ifdef PR_DIAG
+      {
+        int npx = 0, nslots = 0;
+        for (int j = 0; j < PPL; ++j) {
+          npx += __builtin_popcountll(slot[j]);
+          nslots += slot[j] != 0;
+        }
+        if (lane == 0) {
+          atomicAdd(&g_diag[0], 1ull);
+          atomicAdd(&g_diag[1], (unsigned long long)npx);
+          atomicAdd(&g_diag[2], (unsigned long long)nslots);
+          atomicAdd(&g_diag[5], (unsigned long long)__builtin_popcountll(any));
+        }
+      }
+#endif
 
+      // With SLOT_SKIP the work of a pixel slot is skipped when no lane has an active pixel in it
+      // (wave-uniform branches; an inactive pixel contributes exact zeros to every sum).
       float fac[PPL], ra[PPL];
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
-        ra[j] = __builtin_amdgcn_rcpf(1.f - alpha[j]);
-        T[j] = active[j] ? T[j] * ra[j] : T[j];
-        fac[j] = active[j] ? alpha[j] * T[j] : 0.f;
+        ra[j] = 0.f;
+        fac[j] = 0.f;
+        if (!SLOT_SKIP || PPL == 1 || slot[j] != 0ull) {
+          ra[j] = __builtin_amdgcn_rcpf(1.f - alpha[j]);
+          T[j] = active[j] ? T[j] * ra[j] : T[j];
+          fac[j] = active[j] ? alpha[j] * T[j] : 0.f;
+        }
       }
       f2 S2[PPL];
 #pragma unroll
@@ -181,48 +209,61 @@ __global__ void __launch_bounds__(256) raster_bwd_kernel(
       const int gid = L.ids[t];
       float *red = L.red;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (GEOM) c4 = crow[q];
-        const f2 c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w};
-        f2 a01 = splat(0.f), a23 = splat(0.f);
+      for (int q0 = 0; q0 < NQ; q0 += QG) {
+        f2 c01[QG], c23[QG], a01[QG], a23[QG];
+#pragma unroll
+        for (int i = 0; i < QG; ++i) {
+          float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (GEOM) c4 = crow[q0 + i];
+          c01[i] = f2{c4.x, c4.y};
+          c23[i] = f2{c4.z, c4.w};
+          a01[i] = splat(0.f);
+          a23[i] = splat(0.f);
+        }
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
-          if (GEOM) {
-            S2[j] = fma2(c01, vout[j][2 * q], S2[j]);
-            S2[j] = fma2(c23, vout[j][2 * q + 1], S2[j]);
+          if (!SLOT_SKIP || PPL == 1 || slot[j] != 0ull) {
+            const f2 f = splat(fac[j]);
+#pragma unroll
+            for (int i = 0; i < QG; ++i) {
+              if (GEOM) {
+                S2[j] = fma2(c01[i], vout[j][2 * (q0 + i)], S2[j]);
+                S2[j] = fma2(c23[i], vout[j][2 * (q0 + i) + 1], S2[j]);
+              }
+              a01[i] = fma2(f, vout[j][2 * (q0 + i)], a01[i]);
+              a23[i] = fma2(f, vout[j][2 * (q0 + i) + 1], a23[i]);
+            }
           }
-          const f2 f = splat(fac[j]);
-          a01 = fma2(f, vout[j][2 * q], a01);
-          a23 = fma2(f, vout[j][2 * q + 1], a23);
         }
-        red[q * 68 + lane] = quad_fold_rows(a01[0], a01[1], a23[0], a23[1]);
+#pragma unroll
+        for (int i = 0; i < QG; ++i)
+          red[(q0 + i) * 68 + lane] = quad_fold_rows(a01[i][0], a01[i][1], a23[i][0], a23[i][1]);
       }
       if (GEOM) {
-        float S[PPL];
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) S[j] = S2[j][0] + S2[j][1];
         float geo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // x y a b c o |x| |y|
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
-          const int jx = j % Rg::BW, jy = j / Rg::BW;
-          const float v_alpha = S[j] * T[j] - (Bsum[j] - W[j]) * ra[j];
-          Bsum[j] = fmaf(fac[j], S[j], Bsum[j]);
-          const float ar = g.z * e[j];
-          const bool gr = active[j] && (ar <= ALPHA_MAX);
-          const float vs = gr ? -ar * v_alpha : 0.f;  // d loss / d sigma
-          geo[5] += gr ? e[j] * v_alpha : 0.f;
-          const float t1 = vs * dx[jx], t2 = vs * dy[jy];
-          geo[2] = fmaf(t1, dx[jx], geo[2]);
-          geo[3] = fmaf(t1, dy[jy], geo[3]);
-          geo[4] = fmaf(t2, dy[jy], geo[4]);
-          const float gx = 2.f * g.w * dx[jx] + h.x * dy[jy];  // = -log2e * (a dx + b dy)
-          const float gy = h.x * dx[jx] + 2.f * h.y * dy[jy];
-          const float vx = vs * gx, vy = vs * gy;
-          geo[0] += vx;
-          geo[1] += vy;
-          geo[6] += fabsf(vx);
-          geo[7] += fabsf(vy);
+          if (!SLOT_SKIP || PPL == 1 || slot[j] != 0ull) {
+            const int jx = j % Rg::BW, jy = j / Rg::BW;
+            const float S = S2[j][0] + S2[j][1];
+            const float v_alpha = S * T[j] - (Bsum[j] - W[j]) * ra[j];
+            Bsum[j] = fmaf(fac[j], S, Bsum[j]);
+            const float ar = g.z * e[j];
+            const bool gr = active[j] && (ar <= ALPHA_MAX);
+            const float vs = gr ? -ar * v_alpha : 0.f;  // d loss / d sigma
+            geo[5] += gr ? e[j] * v_alpha : 0.f;
+            const float t1 = vs * dx[jx], t2 = vs * dy[jy];
+            geo[2] = fmaf(t1, dx[jx], geo[2]);
+            geo[3] = fmaf(t1, dy[jy], geo[3]);
+            geo[4] = fmaf(t2, dy[jy], geo[4]);
+            const float gx = 2.f * g.w * dx[jx] + h.x * dy[jy];  // = -log2e * (a dx + b dy)
+            const float gy = h.x * dx[jx] + 2.f * h.y * dy[jy];
+            const float vx = vs * gx, vy = vs * gy;
+            geo[0] += vx;
+            geo[1] += vy;
+            geo[6] += fabsf(vx);
+            geo[7] += fabsf(vy);
+          }
         }
         red[NQ * 68 + lane] = quad_fold_rows(geo[0], geo[1], geo[2], geo[3]);
         red[(NQ + 1) * 68 + lane] = quad_fold_rows(geo[4], geo[5], geo[6], geo[7]);
@@ -261,13 +302,24 @@ static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, con
                       int ed_channel, const float *v_render_colors, const float *v_render_alphas, int absgrad,
                       float *v_geom, float *v_colors, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
-  const unsigned grid = (unsigned)((n_regions + 3) / 4);
-  hipLaunchKernelGGL((raster_bwd_kernel<TS, PPL, CD, GEOM>), dim3(grid), dim3(256), 0, stream, (int)n_regions, N, D,
+  const unsigned grid = (unsigned)((n_regions + WPB - 1) / WPB);
+  hipLaunchKernelGGL((raster_bwd_kernel<TS, PPL, CD, GEOM>), dim3(grid), dim3(64 * WPB), 0, stream, (int)n_regions, N, D,
                      ch_off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h,
                      isect_offsets, tile_order, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel,
                      v_render_colors, v_render_alphas, absgrad, v_geom, v_colors);
   return check_launch("raster_bwd_kernel");
 }
+
+#ifdef PR_DIAG
+extern "C" int pr_diag_read(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pr::g_diag), sizeof(pr::g_diag)) != hipSuccess) return -4;
+  if (reset) {
+    unsigned long long z[8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(pr::g_diag), z, sizeof(z)) != hipSuccess) return -4;
+  }
+  return 0;
+}
+#endif
 
 static const int kChunks[] = {4, 8, 16, 24, 32, 36, 48, 64, 72, 100};
 static int pick_chunk(int want) {

@@ -25,24 +25,32 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.999f;
 constexpr float T_STOP = 1e-4f;
 
-// Pixel region owned by one wavefront, and the lane -> pixel map inside it.
+// Pixel region owned by one wavefront, and the lane -> pixel map inside it.  Lane l sits at column
+// l % LX, row l / LX of the region's lane grid (pitch PX, PY pixels) and owns BW x BH pixels spaced SX, SY
+// apart.  With several pixels per lane the lane grid is 16 x 4 and pixel slot j of every lane lies in the
+// j-th 16x4 strip of the region, so one dx serves all of a lane's pixels.  A Gaussian that only reaches part
+// of the tile leaves whole slots without a single active lane (2.8 of 4 slots are live on average at the
+// benchmark shape); skipping such slots with wave-uniform branches was measured SLOWER than doing the
+// arithmetic (1.29 ms vs 1.24 ms backward: ~20 extra branches per Gaussian cost more issue slots than the
+// skipped FMAs), so SLOT_SKIP stays off.
+constexpr bool SLOT_SKIP = false;
 template <int TS, int PPL>
 struct Region;
 template <>
-struct Region<16, 4> {  // whole tile, lane = 2x2 quad
-  static constexpr int WPT = 1, BW = 2, BH = 2, LX = 8, RH = 16;
+struct Region<16, 4> {  // whole tile, lane = one pixel in each of the four 16x4 strips
+  static constexpr int WPT = 1, BW = 1, BH = 4, LX = 16, RH = 16, PX = 1, PY = 1, SX = 1, SY = 4;
 };
 template <>
-struct Region<16, 2> {  // half tile (16x8), lane = 2x1 pair
-  static constexpr int WPT = 2, BW = 2, BH = 1, LX = 8, RH = 8;
+struct Region<16, 2> {  // half tile (16x8), lane = one pixel in each of its two strips
+  static constexpr int WPT = 2, BW = 1, BH = 2, LX = 16, RH = 8, PX = 1, PY = 1, SX = 1, SY = 4;
 };
 template <>
 struct Region<16, 1> {  // quarter tile (16x4), lane = 1 pixel
-  static constexpr int WPT = 4, BW = 1, BH = 1, LX = 16, RH = 4;
+  static constexpr int WPT = 4, BW = 1, BH = 1, LX = 16, RH = 4, PX = 1, PY = 1, SX = 1, SY = 1;
 };
 template <>
 struct Region<8, 1> {  // whole 8x8 tile, lane = 1 pixel
-  static constexpr int WPT = 1, BW = 1, BH = 1, LX = 8, RH = 8;
+  static constexpr int WPT = 1, BW = 1, BH = 1, LX = 8, RH = 8, PX = 1, PY = 1, SX = 1, SY = 1;
 };
 
 // Bijective block-id remap: blocks that share an XCD (equal blockIdx % 8 under round-robin dispatch)
@@ -51,6 +59,11 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
   unsigned q = nb >> 3, r = nb & 7, x = bid & 7, i = bid >> 3;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
+
+// Wavefronts per workgroup.  One: a workgroup's LDS and wave slots are only handed to the next workgroup
+// when ALL of its waves have finished, so with tiles of unequal length multi-wave workgroups leave slots
+// idle behind their slowest tile; nothing here needs a workgroup (no barrier, LDS slices are per wave).
+constexpr int WPB = 1;
 
 constexpr int round4(int x) { return (x + 3) & ~3; }
 // LDS row stride (floats) for staged colours; rows that are a multiple of 32 dwords would put every

@@ -6,7 +6,7 @@
 namespace pr {
 
 template <int TS, int PPL, int CD>
-__global__ void __launch_bounds__(256) raster_fwd_kernel(
+__global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
@@ -15,13 +15,13 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
   using Rg = Region<TS, PPL>;
   constexpr int ROW = color_row(CD);
   constexpr int CDP = round4(CD);
-  __shared__ WaveLds<CD> lds[4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ WaveLds<CD> lds[WPB];
+  const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // Without an explicit order, blocks that share an XCD take a contiguous range of tiles (neighbouring
   // tiles share Gaussians -> one L2).  With one, slot s processes tile tile_order[s]: the caller lists the
   // tiles heaviest first so the last waves of the launch are the cheapest ones.
   const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-  const int region = (int)bid * 4 + wave;
+  const int region = (int)bid * WPB + wave;
   if (region >= n_regions) return;
   WaveLds<CD> &L = lds[wave];
 
@@ -29,8 +29,8 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
   const int n_tiles = tile_w * tile_h;
   const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
   const int ty = tile / tile_w, tx = tile % tile_w;
-  const int x0 = tx * TS + (lane % Rg::LX) * Rg::BW;
-  const int y0 = ty * TS + sub * Rg::RH + (lane / Rg::LX) * Rg::BH;
+  const int x0 = tx * TS + (lane % Rg::LX) * Rg::PX;
+  const int y0 = ty * TS + sub * Rg::RH + (lane / Rg::LX) * Rg::PY;
   const int range_lo = isect_offsets[tile_flat];
   const int range_hi = (tile_flat + 1 < n_regions / Rg::WPT) ? isect_offsets[tile_flat + 1] : n_isects;
 
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
   const float px0 = (float)x0 + 0.5f, py0 = (float)y0 + 0.5f;
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
-    int x = x0 + (j % Rg::BW), y = y0 + (j / Rg::BW);
+    int x = x0 + (j % Rg::BW) * Rg::SX, y = y0 + (j / Rg::BW) * Rg::SY;
     inside[j] = x < width && y < height;
     done[j] = !inside[j];
     T[j] = 1.f;
@@ -71,13 +71,13 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
       float dx[Rg::BW], dy[Rg::BH], adx2[Rg::BW], cdy2[Rg::BH], bdx[Rg::BW];
 #pragma unroll
       for (int i = 0; i < Rg::BW; ++i) {
-        dx[i] = g.x - (px0 + (float)i);
+        dx[i] = g.x - (px0 + (float)(i * Rg::SX));
         adx2[i] = g.w * dx[i] * dx[i];
         bdx[i] = h.x * dx[i];
       }
 #pragma unroll
       for (int i = 0; i < Rg::BH; ++i) {
-        dy[i] = g.y - (py0 + (float)i);
+        dy[i] = g.y - (py0 + (float)(i * Rg::SY));
         cdy2[i] = h.y * dy[i] * dy[i];
       }
       bool all = true;
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) raster_fwd_kernel(
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
     if (!inside[j]) continue;
-    const int x = x0 + (j % Rg::BW), y = y0 + (j / Rg::BW);
+    const int x = x0 + (j % Rg::BW) * Rg::SX, y = y0 + (j / Rg::BW) * Rg::SY;
     const int64_t pix = ((int64_t)cam * height + y) * width + x;
     float *out = render_colors + pix * D + ch_off;
     if (backgrounds) {
@@ -162,8 +162,8 @@ static int launch_fwd(int C, int N, int D, int ch_off, const float *means2d, con
                       int64_t n_isects, int ed_channel,
                       float *render_colors, float *render_alphas, int32_t *last_ids, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
-  const unsigned grid = (unsigned)((n_regions + 3) / 4);
-  hipLaunchKernelGGL((raster_fwd_kernel<TS, PPL, CD>), dim3(grid), dim3(256), 0, stream, (int)n_regions, N, D, ch_off,
+  const unsigned grid = (unsigned)((n_regions + WPB - 1) / WPB);
+  hipLaunchKernelGGL((raster_fwd_kernel<TS, PPL, CD>), dim3(grid), dim3(64 * WPB), 0, stream, (int)n_regions, N, D, ch_off,
                      means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
                      tile_order, flatten_ids, (int)n_isects, ed_channel, render_colors, render_alphas, last_ids);
   return check_launch("raster_fwd_kernel");

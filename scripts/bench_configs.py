@@ -8,7 +8,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pogs_amd import rendering, tracking  # noqa: E402
 from pogs_amd.scenes import make_scene  # noqa: E402
 
