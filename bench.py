@@ -174,7 +174,7 @@ def main():
             r, a, meta = rendering.rasterization(colors=params["sh"], sh_degree=3, render_mode="RGB+ED",
                                                  absgrad=True, features=params["features"], **common)
             torch.autograd.backward([r, a], [v_colors, v_alpha])
-        info["n_isects"] = meta["isect_ids"].numel()
+        info["n_isects"] = meta["flatten_ids"].numel()
         info["tile_bits"] = (meta["tile_width"] * meta["tile_height"]).bit_length()
         if world > 1:
             grads.all_reduce_mean()

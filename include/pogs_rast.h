@@ -88,12 +88,15 @@ int pr_isect_count(int C, int N, const float *means2d, const int32_t *radii, int
                    size_t scratch_bytes, void *stream);
 /* Phase 2: key = cam<<(32+tile_bits) | tile<<32 | float_bits(depth), value = flat index, in stable
  * ascending key order (ties by ascending flat index).  tiles_per_gauss is phase 1's output.
- * Out: isect_ids[n_isects] int64, flatten_ids[n_isects] int32. */
+ * Out: flatten_ids[n_isects] int32; isect_ids[n_isects] int64 (may be NULL: the 64-bit keys are only
+ * materialised for callers that want gsplat's `isect_ids`); isect_offsets[C,tile_h,tile_w] int32 (may be
+ * NULL), the same table pr_isect_offsets derives from isect_ids, written here straight from the sorted
+ * tile keys. */
 size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects);
 int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                        const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h, int64_t n_isects,
-                       int64_t *isect_ids, int32_t *flatten_ids, void *scratch, size_t scratch_bytes,
-                       void *stream);
+                       int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets, void *scratch,
+                       size_t scratch_bytes, void *stream);
 /* isect_offsets[C,tile_h,tile_w] int32: index of the first intersection of every (camera, tile). */
 int pr_isect_offsets(int64_t n_isects, const int64_t *isect_ids, int C, int tile_w, int tile_h,
                      int32_t *isect_offsets, void *stream);

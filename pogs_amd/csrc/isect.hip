@@ -115,6 +115,11 @@ extern "C" int pr_isect_count(int C, int N, const float *means2d, const int32_t 
 // GAUSSIANS by depth bits first (stable, so ties keep ascending flat index), emitting intersections in
 // that order with 32-bit (camera | tile) keys, and finishing with a stable sort over only the tb+cb tile
 // bits (2 passes of 8-byte pairs at 1080p instead of 6 passes of 12-byte pairs).
+// rocPRIM's default picks a block-sort + ten merge passes below 1M items (~180 us for the depth sort of 1M
+// Gaussians); Onesweep does the same in four passes (~40 us), so the merge path is limited to small inputs.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                              rocprim::default_config, 32768>;
+
 struct Phase2Layout {
   size_t dkeys_in, dkeys_out, dvals_in, dvals_out, starts, tkeys_in, tkeys_out, tvals_in, temp, temp_bytes, total;
 };
@@ -141,9 +146,9 @@ static Phase2Layout phase2_layout(int64_t cn, int64_t n_isects) {
   L.tkeys_out = take((size_t)n_isects * 4);
   L.tvals_in = take((size_t)n_isects * 4);
   size_t t1 = 0, t2 = 0, t3 = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, t1, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+  (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                   (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)cn, 0u, 32u);
-  (void)rocprim::radix_sort_pairs(nullptr, t2, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+  (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, t2, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                   (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n_isects, 0u, 32u);
   auto it = rocprim::make_transform_iterator((const uint32_t *)nullptr, TilesOf{nullptr});
   (void)rocprim::exclusive_scan(nullptr, t3, it, (uint32_t *)nullptr, 0u, (size_t)cn, rocprim::plus<uint32_t>());
@@ -162,28 +167,76 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t total, const fl
   vals[idx] = (uint32_t)idx;
 }
 
-// One lane per Gaussian in depth order; writes its (camera|tile) keys and its flat index.
+// Emits the (camera|tile) key and the flat Gaussian index of every intersection, Gaussians in depth order.
+// Load-balanced expansion per wavefront: the 64 Gaussians of a wave own a contiguous output range
+// [start of lane 0, end of lane 63); the wave walks that range 64 outputs at a time, every lane finding the
+// Gaussian its output belongs to by a 6-step search over the lanes' start offsets -- so the 4-byte writes
+// are coalesced however uneven the tile counts are.
 __global__ void __launch_bounds__(256) isect_emit_sorted_kernel(
     int64_t total, int N, const uint32_t *__restrict__ order, const uint32_t *__restrict__ starts,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii, float ts, int tile_w, int tile_h,
     int tile_bits, int64_t n_isects, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= total) return;
-  const uint32_t idx = order[r];
-  const int rad = radii[idx];
-  if (rad <= 0) return;
-  TileRect t = tile_rect(means2d[2 * (int64_t)idx], means2d[2 * (int64_t)idx + 1], rad, ts, tile_w, tile_h);
-  if ((t.x1 - t.x0) * (t.y1 - t.y0) <= 0) return;
-  int64_t k = starts[r];
-  const uint32_t hi = (uint32_t)(idx / (uint32_t)N) << tile_bits;
-  for (int y = t.y0; y < t.y1; ++y)
-    for (int x = t.x0; x < t.x1; ++x) {
-      if (k < n_isects) {
-        keys[k] = hi | (uint32_t)(y * tile_w + x);
-        vals[k] = idx;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  uint32_t idx = 0, start = (uint32_t)n_isects;
+  int x0 = 0, y0 = 0, w = 1, cnt = 0;
+  if (r < total) {
+    idx = order[r];
+    start = starts[r];
+    const int rad = radii[idx];
+    if (rad > 0) {
+      TileRect t = tile_rect(means2d[2 * (int64_t)idx], means2d[2 * (int64_t)idx + 1], rad, ts, tile_w, tile_h);
+      const int c = (t.x1 - t.x0) * (t.y1 - t.y0);
+      if (c > 0) {
+        x0 = t.x0;
+        y0 = t.y0;
+        w = t.x1 - t.x0;
+        cnt = c;
       }
-      ++k;
     }
+  }
+  const uint32_t hi = (idx / (uint32_t)N) << tile_bits;
+  const uint32_t begin = (uint32_t)__builtin_amdgcn_readlane((int)start, 0);
+  uint32_t end = (uint32_t)__builtin_amdgcn_readlane((int)(start + (uint32_t)cnt), 63);
+  if ((int64_t)end > n_isects) end = (uint32_t)n_isects;
+  for (uint32_t k0 = begin; k0 < end; k0 += 64) {
+    const uint32_t k = k0 + (uint32_t)lane;
+    int j = 0;  // last lane whose start is <= k
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) {
+      const uint32_t sc = (uint32_t)__shfl((int)start, (j + step) & 63);
+      if (j + step < 64 && sc <= k) j += step;
+    }
+    const uint32_t sj = (uint32_t)__shfl((int)start, j);
+    const int xj = __shfl(x0, j), yj = __shfl(y0, j), wj = __shfl(w, j);
+    const uint32_t hj = (uint32_t)__shfl((int)hi, j), ij = (uint32_t)__shfl((int)idx, j);
+    if (k < end) {
+      const int t = (int)(k - sj);
+      const int ty = t / wj, tx = t - ty * wj;
+      keys[k] = hj | (uint32_t)((yj + ty) * tile_w + (xj + tx));
+      vals[k] = ij;
+    }
+  }
+}
+
+// Start of every tile's range in the sorted list, from the sorted 32-bit (camera|tile) keys.
+__global__ void __launch_bounds__(256) tile_offsets_kernel(int64_t n_isects, const uint32_t *__restrict__ tkeys,
+                                                           int n_tiles_total, int tile_bits, int n_tiles,
+                                                           int32_t *__restrict__ offsets) {
+  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_isects) return;
+  const uint32_t mask = (1u << tile_bits) - 1u;
+  const uint32_t hc = tkeys[k];
+  const int cur = (int)(hc >> tile_bits) * n_tiles + (int)(hc & mask);
+  if (k == 0) {
+    for (int t = 0; t <= cur; ++t) offsets[t] = 0;
+  } else {
+    const uint32_t hp = tkeys[k - 1];
+    const int prev = (int)(hp >> tile_bits) * n_tiles + (int)(hp & mask);
+    for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)k;
+  }
+  if (k == n_isects - 1)
+    for (int t = cur + 1; t < n_tiles_total; ++t) offsets[t] = (int32_t)n_isects;
 }
 
 __global__ void __launch_bounds__(256) isect_ids_kernel(int64_t n_isects, const uint32_t *__restrict__ tkeys,
@@ -203,13 +256,17 @@ extern "C" size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects) {
 
 extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                                   const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h,
-                                  int64_t n_isects, int64_t *isect_ids, int32_t *flatten_ids, void *scratch,
-                                  size_t scratch_bytes, void *stream) {
+                                  int64_t n_isects, int64_t *isect_ids, int32_t *flatten_ids,
+                                  int32_t *isect_offsets, void *scratch, size_t scratch_bytes, void *stream) {
   if (C < 0 || N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0) return PR_EINVAL;
   const int64_t total = (int64_t)C * N;
-  if (total == 0 || n_isects == 0) return PR_OK;
+  if (total == 0 || n_isects == 0) {
+    if (isect_offsets && (int64_t)C * tile_w * tile_h > 0)
+      PR_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)C * tile_w * tile_h * 4, (hipStream_t)stream));
+    return PR_OK;
+  }
   if (n_isects > (int64_t)2147483647 || total > (int64_t)2147483647) return PR_EUNSUPPORTED;
-  if (!means2d || !radii || !depths || !tiles_per_gauss || !isect_ids || !flatten_ids || !scratch) return PR_EINVAL;
+  if (!means2d || !radii || !depths || !tiles_per_gauss || !flatten_ids || !scratch) return PR_EINVAL;
   const int tile_bits = bit_length((int64_t)tile_w * tile_h);
   const int cam_bits = bit_length((int64_t)C - 1);
   if (tile_bits + cam_bits > 32) return PR_EUNSUPPORTED;
@@ -228,7 +285,7 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
   int rc = check_launch("depth_keys_kernel");
   if (rc) return rc;
   size_t tb = L.temp_bytes;
-  PR_HIP(rocprim::radix_sort_pairs(temp, tb, (const uint32_t *)dk_in, dk_out, (const uint32_t *)dv_in, dv_out,
+  PR_HIP(rocprim::radix_sort_pairs<SortConfig>(temp, tb, (const uint32_t *)dk_in, dk_out, (const uint32_t *)dv_in, dv_out,
                                    (size_t)total, 0u, 32u, st));
   auto it = rocprim::make_transform_iterator((const uint32_t *)dv_out, TilesOf{tiles_per_gauss});
   tb = L.temp_bytes;
@@ -238,13 +295,22 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
   rc = check_launch("isect_emit_sorted_kernel");
   if (rc) return rc;
   tb = L.temp_bytes;
-  PR_HIP(rocprim::radix_sort_pairs(temp, tb, (const uint32_t *)tk_in, tk_out, (const uint32_t *)tv_in,
+  PR_HIP(rocprim::radix_sort_pairs<SortConfig>(temp, tb, (const uint32_t *)tk_in, tk_out, (const uint32_t *)tv_in,
                                    (uint32_t *)flatten_ids, (size_t)n_isects, 0u, (unsigned)(tile_bits + cam_bits),
                                    st));
   const unsigned grid_i = (unsigned)((n_isects + 255) / 256);
-  hipLaunchKernelGGL(isect_ids_kernel, dim3(grid_i), dim3(256), 0, st, n_isects, tk_out, flatten_ids, depths,
-                     isect_ids);
-  return check_launch("isect_ids_kernel");
+  if (isect_offsets) {
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(grid_i), dim3(256), 0, st, n_isects, tk_out,
+                       (int)((int64_t)C * tile_w * tile_h), tile_bits, tile_w * tile_h, isect_offsets);
+    rc = check_launch("tile_offsets_kernel");
+    if (rc) return rc;
+  }
+  if (isect_ids) {
+    hipLaunchKernelGGL(isect_ids_kernel, dim3(grid_i), dim3(256), 0, st, n_isects, tk_out, flatten_ids, depths,
+                       isect_ids);
+    rc = check_launch("isect_ids_kernel");
+  }
+  return rc;
 }
 
 extern "C" int pr_isect_offsets(int64_t n_isects, const int64_t *isect_ids, int C, int tile_w, int tile_h,

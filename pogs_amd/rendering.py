@@ -186,18 +186,21 @@ class _SphericalHarmonics(torch.autograd.Function):
         return None, v_means, v_campos, (v_coeffs if ctx.needs_input_grad[3] else None), None, None
 
 
-def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
-                tile_height: int) -> Tuple[Tensor, Tensor, Tensor]:
-    """Stands in for gsplat ``isect_tiles`` (non-packed, sorted).  means2d [C,N,2], radii [C,N] int32,
-    depths [C,N] -> tiles_per_gauss [C,N] int32, isect_ids [I] int64 (sorted), flatten_ids [I] int32."""
+def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int, tile_height: int,
+               want_ids: bool, want_offsets: bool):
+    """Tile binning: -> tiles_per_gauss [C,N] int32, isect_ids [I] int64 or None, flatten_ids [I] int32,
+    isect_offsets [C,th,tw] int32 or None."""
     lib = _lib.load()
     C, N = radii.shape
     dev = means2d.device
     means2d, radii, depths = means2d.detach().contiguous(), radii.contiguous(), depths.detach().contiguous()
     tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
+    offsets = torch.empty(C, tile_height, tile_width, dtype=torch.int32, device=dev) if want_offsets else None
     if C * N == 0:
-        return (tiles_per_gauss, torch.empty(0, dtype=torch.int64, device=dev),
-                torch.empty(0, dtype=torch.int32, device=dev))
+        if offsets is not None:
+            offsets.zero_()
+        return (tiles_per_gauss, torch.empty(0, dtype=torch.int64, device=dev) if want_ids else None,
+                torch.empty(0, dtype=torch.int32, device=dev), offsets)
     cum = torch.empty(C * N, dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
         nb = lib.pr_isect_count_scratch_bytes(C, N)
@@ -205,15 +208,68 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
         _call("pr_isect_count", C, N, _ptr(means2d), _ptr(radii), tile_size, tile_width, tile_height,
                                       _ptr(tiles_per_gauss), _ptr(cum), _ptr(scratch), nb, _stream())
         n_isects = int(cum[-1].item())  # the path's one device->host read
-        isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
+        isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_ids else None
         flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
-        if n_isects > 0:
-            nb = lib.pr_isect_sort_scratch_bytes(C, N, n_isects)
-            scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-            _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(tiles_per_gauss), tile_size,
-                                              tile_width, tile_height, n_isects, _ptr(isect_ids), _ptr(flatten_ids),
-                                              _ptr(scratch), nb, _stream())
+        nb = lib.pr_isect_sort_scratch_bytes(C, N, n_isects)
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(tiles_per_gauss), tile_size,
+                                          tile_width, tile_height, n_isects, _ptr(isect_ids), _ptr(flatten_ids),
+                                          _ptr(offsets), _ptr(scratch), nb, _stream())
+    return tiles_per_gauss, isect_ids, flatten_ids, offsets
+
+
+def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
+                tile_height: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """Stands in for gsplat ``isect_tiles`` (non-packed, sorted).  means2d [C,N,2], radii [C,N] int32,
+    depths [C,N] -> tiles_per_gauss [C,N] int32, isect_ids [I] int64 (sorted), flatten_ids [I] int32."""
+    tiles_per_gauss, isect_ids, flatten_ids, _ = _bin_tiles(means2d, radii, depths, tile_size, tile_width,
+                                                            tile_height, True, False)
     return tiles_per_gauss, isect_ids, flatten_ids
+
+
+def _isect_ids_from_lists(isect_offsets: Tensor, flatten_ids: Tensor, depths: Tensor) -> Tensor:
+    """gsplat's 64-bit intersection keys, camera << (32 + tile_bits) | tile << 32 | float_bits(depth), rebuilt
+    from the tile lists: intersection k belongs to the last tile whose range starts at or before k."""
+    C, th, tw = isect_offsets.shape
+    n_tiles = th * tw
+    tile_bits = int(n_tiles).bit_length()
+    k = torch.arange(flatten_ids.numel(), device=flatten_ids.device, dtype=torch.int32)
+    tile_flat = torch.searchsorted(isect_offsets.flatten(), k, right=True).long() - 1
+    hi = ((tile_flat // n_tiles) << tile_bits) | (tile_flat % n_tiles)
+    d = depths.detach().contiguous().view(-1).view(torch.int32)[flatten_ids.long()].long() & 0xFFFFFFFF
+    return (hi << 32) | d
+
+
+class RenderMeta(dict):
+    """The ``meta`` dict of ``rasterization``.  Every gsplat key is present; ``isect_ids`` -- which nothing
+    on the render path reads -- is only materialised when it is first asked for."""
+
+    _LAZY = "isect_ids"
+
+    def _resolve(self):
+        v = dict.__getitem__(self, self._LAZY)
+        if callable(v):
+            v = v()
+            dict.__setitem__(self, self._LAZY, v)
+        return v
+
+    def __getitem__(self, key):
+        return self._resolve() if key == self._LAZY else dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def items(self):
+        self._resolve()
+        return dict.items(self)
+
+    def values(self):
+        self._resolve()
+        return dict.values(self)
+
+    def copy(self):
+        self._resolve()
+        return dict(self)
 
 
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
@@ -505,8 +561,8 @@ def rasterization(
 
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
-    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height)
-    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
+    tiles_per_gauss, _, flatten_ids, isect_offsets = _bin_tiles(means2d, radii, depths, tile_size, tile_width,
+                                                                tile_height, False, True)
 
     # expected depth (ED): the depth channel is divided by max(alpha, 1e-10) inside the kernels
     ed_channel = cols.shape[-1] - 1 if render_mode in ("ED", "RGB+ED") else -1
@@ -514,11 +570,12 @@ def rasterization(
         means2d, conics, cols, opac, width, height, tile_size, isect_offsets, flatten_ids, backgrounds=bgs,
         absgrad=absgrad, ed_channel=ed_channel)
 
-    meta = {
+    meta = RenderMeta({
         "camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths,
         "conics": conics, "opacities": opac, "tile_width": tile_width, "tile_height": tile_height,
-        "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids, "flatten_ids": flatten_ids,
+        "tiles_per_gauss": tiles_per_gauss,
+        "isect_ids": lambda: _isect_ids_from_lists(isect_offsets, flatten_ids, depths), "flatten_ids": flatten_ids,
         "isect_offsets": isect_offsets, "width": width, "height": height, "tile_size": tile_size,
         "n_cameras": C,
-    }
+    })
     return render_colors, render_alphas, meta

@@ -151,6 +151,10 @@ def test_isect_bit_exact(gpu, tile_size, views):
     assert torch.equal(flat.cpu(), flat_r)
     assert torch.equal(offs.cpu(), offs_r)
     assert ids.dtype == torch.int64 and flat.dtype == torch.int32 and offs.dtype == torch.int32
+    # the render path's variant: no 64-bit keys, offsets straight from the sorted tile keys, keys rebuilt lazily
+    tpg2, none, flat2, offs2 = rd._bin_tiles(means2d, radii, depths, tile_size, tw, th, False, True)
+    assert none is None and torch.equal(tpg2, tpg) and torch.equal(flat2, flat) and torch.equal(offs2, offs)
+    assert torch.equal(rd._isect_ids_from_lists(offs2, flat2, depths), ids)
 
 
 def test_isect_empty(gpu):
@@ -268,6 +272,7 @@ def test_rasterization_end_to_end(gpu, mode, tile_size, antialiased):
     assert torch.equal(meta["isect_ids"].cpu(), meta_r["isect_ids"]), "binning differs from the float64 oracle"
     assert_image_close(out, out_r, amb, "render_colors")
     assert_image_close(alpha, alpha_r, amb, "render_alphas")
+    assert isinstance(meta, dict) and "isect_ids" in meta and torch.is_tensor(meta.get("isect_ids"))
     assert set(meta.keys()) >= {"camera_ids", "gaussian_ids", "radii", "means2d", "depths", "conics", "opacities",
                                 "tile_width", "tile_height", "tiles_per_gauss", "isect_ids", "flatten_ids",
                                 "isect_offsets", "width", "height", "tile_size", "n_cameras"}
