@@ -115,13 +115,15 @@ extern "C" int pr_isect_count(int C, int N, const float *means2d, const int32_t 
 // GAUSSIANS by depth bits first (stable, so ties keep ascending flat index), emitting intersections in
 // that order with 32-bit (camera | tile) keys, and finishing with a stable sort over only the tb+cb tile
 // bits (2 passes of 8-byte pairs at 1080p instead of 6 passes of 12-byte pairs).
-// rocPRIM's default picks a block-sort + ten merge passes below 1M items (~180 us for the depth sort of 1M
-// Gaussians); Onesweep does the same in four passes (~40 us), so the merge path is limited to small inputs.
+// rocPRIM's default switches from block-sort + merge passes to Onesweep above 1M items; measured on gfx950
+// for (u32,u32) pairs the merge path wins at 200k items (60 vs 120 us) and loses from about 1M on
+// (159 vs 138 us), so the switch point is moved to 512k.
 using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                              rocprim::default_config, 32768>;
+                                              rocprim::default_config, 512 * 1024>;
 
 struct Phase2Layout {
-  size_t dkeys_in, dkeys_out, dvals_in, dvals_out, starts, tkeys_in, tkeys_out, tvals_in, temp, temp_bytes, total;
+  size_t dkeys_in, dkeys_out, dvals_in, dvals_out, starts, tkeys_in, tkeys_out, tvals_in, lkeys_in, lkeys_out,
+      lvals_in, temp, temp_bytes, total;
 };
 
 struct TilesOf {
@@ -129,7 +131,7 @@ struct TilesOf {
   __device__ __host__ uint32_t operator()(uint32_t flat) const { return (uint32_t)tpg[flat]; }
 };
 
-static Phase2Layout phase2_layout(int64_t cn, int64_t n_isects) {
+static Phase2Layout phase2_layout(int64_t cn, int64_t n_isects, int64_t n_tiles) {
   Phase2Layout L;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -145,14 +147,21 @@ static Phase2Layout phase2_layout(int64_t cn, int64_t n_isects) {
   L.tkeys_in = take((size_t)n_isects * 4);
   L.tkeys_out = take((size_t)n_isects * 4);
   L.tvals_in = take((size_t)n_isects * 4);
-  size_t t1 = 0, t2 = 0, t3 = 0;
+  L.lkeys_in = take((size_t)n_tiles * 4);
+  L.lkeys_out = take((size_t)n_tiles * 4);
+  L.lvals_in = take((size_t)n_tiles * 4);
+  size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
   (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                   (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)cn, 0u, 32u);
   (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, t2, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                   (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n_isects, 0u, 32u);
   auto it = rocprim::make_transform_iterator((const uint32_t *)nullptr, TilesOf{nullptr});
   (void)rocprim::exclusive_scan(nullptr, t3, it, (uint32_t *)nullptr, 0u, (size_t)cn, rocprim::plus<uint32_t>());
+  if (n_tiles > 0)
+    (void)rocprim::radix_sort_pairs_desc(nullptr, t4, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                         (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n_tiles, 0u, 32u);
   L.temp_bytes = t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3);
+  if (t4 > L.temp_bytes) L.temp_bytes = t4;
   L.temp = take(L.temp_bytes);
   L.total = off + 256;
   return L;
@@ -239,6 +248,17 @@ __global__ void __launch_bounds__(256) tile_offsets_kernel(int64_t n_isects, con
     for (int t = cur + 1; t < n_tiles_total; ++t) offsets[t] = (int32_t)n_isects;
 }
 
+// Sort keys for the launch order of the compositing kernels: the length of every tile's list.
+__global__ void __launch_bounds__(256) tile_length_kernel(int n_tiles_total, const int32_t *__restrict__ offsets,
+                                                          int64_t n_isects, uint32_t *__restrict__ keys,
+                                                          uint32_t *__restrict__ vals) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tiles_total) return;
+  const int32_t hi = t + 1 < n_tiles_total ? offsets[t + 1] : (int32_t)n_isects;
+  keys[t] = (uint32_t)(hi - offsets[t]);
+  vals[t] = (uint32_t)t;
+}
+
 __global__ void __launch_bounds__(256) isect_ids_kernel(int64_t n_isects, const uint32_t *__restrict__ tkeys,
                                                         const int32_t *__restrict__ flatten_ids,
                                                         const float *__restrict__ depths,
@@ -249,20 +269,33 @@ __global__ void __launch_bounds__(256) isect_ids_kernel(int64_t n_isects, const 
   isect_ids[k] = ((int64_t)tkeys[k] << 32) | (int64_t)d;
 }
 
-extern "C" size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects) {
+extern "C" size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects, int64_t n_tiles_total) {
   if (n_isects <= 0 || (int64_t)C * N <= 0) return 256;
-  return phase2_layout((int64_t)C * N, n_isects).total;
+  return phase2_layout((int64_t)C * N, n_isects, n_tiles_total > 0 ? n_tiles_total : 0).total;
 }
 
 extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                                   const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h,
                                   int64_t n_isects, int64_t *isect_ids, int32_t *flatten_ids,
-                                  int32_t *isect_offsets, void *scratch, size_t scratch_bytes, void *stream) {
+                                  int32_t *isect_offsets, int32_t *tile_order, void *scratch,
+                                  size_t scratch_bytes, void *stream) {
   if (C < 0 || N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0) return PR_EINVAL;
   const int64_t total = (int64_t)C * N;
+  if (tile_order && !isect_offsets) return PR_EINVAL;  // the order is derived from the offsets table
+  const int64_t n_tiles_total = (int64_t)C * tile_w * tile_h;
+  if (n_tiles_total > (int64_t)2147483647) return PR_EUNSUPPORTED;
   if (total == 0 || n_isects == 0) {
-    if (isect_offsets && (int64_t)C * tile_w * tile_h > 0)
-      PR_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)C * tile_w * tile_h * 4, (hipStream_t)stream));
+    if (isect_offsets && n_tiles_total > 0) {
+      PR_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)n_tiles_total * 4, (hipStream_t)stream));
+      if (tile_order) {
+        if (!scratch || scratch_bytes < (size_t)n_tiles_total * 8) return PR_ESCRATCH;
+        uint32_t *k = (uint32_t *)scratch;  // all lengths are zero: the identity order
+        hipLaunchKernelGGL(tile_length_kernel, dim3((unsigned)((n_tiles_total + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, (int)n_tiles_total, isect_offsets, (int64_t)0, k,
+                           (uint32_t *)tile_order);
+        return check_launch("tile_length_kernel");
+      }
+    }
     return PR_OK;
   }
   if (n_isects > (int64_t)2147483647 || total > (int64_t)2147483647) return PR_EUNSUPPORTED;
@@ -270,7 +303,7 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
   const int tile_bits = bit_length((int64_t)tile_w * tile_h);
   const int cam_bits = bit_length((int64_t)C - 1);
   if (tile_bits + cam_bits > 32) return PR_EUNSUPPORTED;
-  const Phase2Layout L = phase2_layout(total, n_isects);
+  const Phase2Layout L = phase2_layout(total, n_isects, tile_order ? n_tiles_total : 0);
   if (L.total > scratch_bytes) return PR_ESCRATCH;
   char *base = (char *)scratch;
   uint32_t *dk_in = (uint32_t *)(base + L.dkeys_in), *dk_out = (uint32_t *)(base + L.dkeys_out);
@@ -304,6 +337,18 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
                        (int)((int64_t)C * tile_w * tile_h), tile_bits, tile_w * tile_h, isect_offsets);
     rc = check_launch("tile_offsets_kernel");
     if (rc) return rc;
+  }
+  if (tile_order) {
+    uint32_t *lk_in = (uint32_t *)(base + L.lkeys_in), *lk_out = (uint32_t *)(base + L.lkeys_out);
+    uint32_t *lv_in = (uint32_t *)(base + L.lvals_in);
+    hipLaunchKernelGGL(tile_length_kernel, dim3((unsigned)((n_tiles_total + 255) / 256)), dim3(256), 0, st,
+                       (int)n_tiles_total, isect_offsets, n_isects, lk_in, lv_in);
+    rc = check_launch("tile_length_kernel");
+    if (rc) return rc;
+    tb = L.temp_bytes;
+    PR_HIP(rocprim::radix_sort_pairs_desc(temp, tb, (const uint32_t *)lk_in, lk_out, (const uint32_t *)lv_in,
+                                          (uint32_t *)tile_order, (size_t)n_tiles_total, 0u,
+                                          (unsigned)bit_length(n_isects), st));
   }
   if (isect_ids) {
     hipLaunchKernelGGL(isect_ids_kernel, dim3(grid_i), dim3(256), 0, st, n_isects, tk_out, flatten_ids, depths,

@@ -186,21 +186,30 @@ class _SphericalHarmonics(torch.autograd.Function):
         return None, v_means, v_campos, (v_coeffs if ctx.needs_input_grad[3] else None), None, None
 
 
+_ORDER_MIN_TILES = 2048  # fewer tiles than wave slots: nothing to balance
+
+
 def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int, tile_height: int,
-               want_ids: bool, want_offsets: bool):
+               want_ids: bool, want_offsets: bool, want_order: bool = False):
     """Tile binning: -> tiles_per_gauss [C,N] int32, isect_ids [I] int64 or None, flatten_ids [I] int32,
-    isect_offsets [C,th,tw] int32 or None."""
+    isect_offsets [C,th,tw] int32 or None[, tile_order [C*th*tw] int32 or None when ``want_order``: tiles
+    sorted by list length, longest first (None below ``_ORDER_MIN_TILES`` tiles)]."""
     lib = _lib.load()
     C, N = radii.shape
     dev = means2d.device
     means2d, radii, depths = means2d.detach().contiguous(), radii.contiguous(), depths.detach().contiguous()
     tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
     offsets = torch.empty(C, tile_height, tile_width, dtype=torch.int32, device=dev) if want_offsets else None
+    n_tiles = C * tile_height * tile_width
+    order = None
+    if want_order and want_offsets and n_tiles >= _ORDER_MIN_TILES and C * N > 0:
+        order = torch.empty(n_tiles, dtype=torch.int32, device=dev)
     if C * N == 0:
         if offsets is not None:
             offsets.zero_()
-        return (tiles_per_gauss, torch.empty(0, dtype=torch.int64, device=dev) if want_ids else None,
-                torch.empty(0, dtype=torch.int32, device=dev), offsets)
+        out = (tiles_per_gauss, torch.empty(0, dtype=torch.int64, device=dev) if want_ids else None,
+               torch.empty(0, dtype=torch.int32, device=dev), offsets)
+        return out + (None,) if want_order else out
     cum = torch.empty(C * N, dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
         nb = lib.pr_isect_count_scratch_bytes(C, N)
@@ -210,11 +219,14 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
         n_isects = int(cum[-1].item())  # the path's one device->host read
         isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_ids else None
         flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
-        nb = lib.pr_isect_sort_scratch_bytes(C, N, n_isects)
+        nb = max(lib.pr_isect_sort_scratch_bytes(C, N, n_isects, n_tiles if order is not None else 0),
+                 8 * n_tiles if order is not None else 0)
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
         _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(tiles_per_gauss), tile_size,
                                           tile_width, tile_height, n_isects, _ptr(isect_ids), _ptr(flatten_ids),
-                                          _ptr(offsets), _ptr(scratch), nb, _stream())
+                                          _ptr(offsets), _ptr(order), _ptr(scratch), nb, _stream())
+    if want_order:
+        return tiles_per_gauss, isect_ids, flatten_ids, offsets, order
     return tiles_per_gauss, isect_ids, flatten_ids, offsets
 
 
@@ -287,7 +299,7 @@ def _tile_order(isect_offsets: Tensor, n_isects: int) -> Optional[Tensor]:
     """Flat tile indices sorted by list length, longest first: wavefronts pick the heavy tiles up first so
     that the launch does not end on a few long ones (results do not depend on the order)."""
     o = isect_offsets.flatten()
-    if o.numel() < 2048:  # fewer tiles than wave slots: nothing to balance
+    if o.numel() < _ORDER_MIN_TILES:
         return None
     ends = torch.cat([o[1:], o.new_tensor([n_isects])])
     return torch.argsort(ends - o, descending=True).to(torch.int32)
@@ -298,7 +310,7 @@ class _Rasterize(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size, isect_offsets,
-                flatten_ids, absgrad, ed_channel):
+                flatten_ids, absgrad, ed_channel, tile_order):
         lib = _lib.load()
         C, N, D = colors.shape
         dev = means2d.device
@@ -309,7 +321,8 @@ class _Rasterize(torch.autograd.Function):
         render_colors = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
         render_alphas = torch.empty(C, height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
-        tile_order = _tile_order(isect_offsets, flatten_ids.numel())
+        if tile_order is None:
+            tile_order = _tile_order(isect_offsets, flatten_ids.numel())
         with torch.cuda.device(dev):
             _call("pr_raster_fwd", C, N, D, _ptr(means2d_c), _ptr(conics), _ptr(colors), _ptr(opacities),
                                          _ptr(backgrounds), width, height, tile_size, tw, th, _ptr(isect_offsets),
@@ -362,18 +375,19 @@ class _Rasterize(torch.autograd.Function):
         ctx.means2d_obj = None
         return (v_means2d if ctx.needs_input_grad[0] else None, v_conics if ctx.needs_input_grad[1] else None,
                 v_colors, v_opacities if ctx.needs_input_grad[3] else None, v_backgrounds, None, None, None, None,
-                None, None, None)
+                None, None, None, None)
 
 
 def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor, image_width: int,
                         image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
                         backgrounds: Optional[Tensor] = None, absgrad: bool = False,
-                        ed_channel: int = -1) -> Tuple[Tensor, Tensor]:
+                        ed_channel: int = -1, tile_order: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """Stands in for gsplat ``rasterize_to_pixels`` (non-packed): [C,N,*] inputs ->
     render_colors [C,H,W,D], render_alphas [C,H,W,1].  ``ed_channel`` (extension): index of a depth
-    channel to output as expected depth, accumulated depth / max(alpha, 1e-10); -1 = none."""
+    channel to output as expected depth, accumulated depth / max(alpha, 1e-10); -1 = none.  ``tile_order``
+    (extension): launch order of the tiles as ``_bin_tiles`` returns it; derived here when not given."""
     return _Rasterize.apply(means2d, conics, colors, opacities, backgrounds, image_width, image_height, tile_size,
-                            isect_offsets, flatten_ids, absgrad, int(ed_channel))
+                            isect_offsets, flatten_ids, absgrad, int(ed_channel), tile_order)
 
 
 class _AssembleColors(torch.autograd.Function):
@@ -561,14 +575,14 @@ def rasterization(
 
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
-    tiles_per_gauss, _, flatten_ids, isect_offsets = _bin_tiles(means2d, radii, depths, tile_size, tile_width,
-                                                                tile_height, False, True)
+    tiles_per_gauss, _, flatten_ids, isect_offsets, tile_order = _bin_tiles(
+        means2d, radii, depths, tile_size, tile_width, tile_height, False, True, True)
 
     # expected depth (ED): the depth channel is divided by max(alpha, 1e-10) inside the kernels
     ed_channel = cols.shape[-1] - 1 if render_mode in ("ED", "RGB+ED") else -1
     render_colors, render_alphas = rasterize_to_pixels(
         means2d, conics, cols, opac, width, height, tile_size, isect_offsets, flatten_ids, backgrounds=bgs,
-        absgrad=absgrad, ed_channel=ed_channel)
+        absgrad=absgrad, ed_channel=ed_channel, tile_order=tile_order)
 
     meta = RenderMeta({
         "camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths,

@@ -157,6 +157,27 @@ def test_isect_bit_exact(gpu, tile_size, views):
     assert torch.equal(rd._isect_ids_from_lists(offs2, flat2, depths), ids)
 
 
+def test_tile_order_is_a_permutation_by_descending_length(gpu):
+    rd = _rendering()
+    sc = small_scene(n=4000, w=1024, h=640, seed=5, lo=0.01, hi=0.2)
+    a = scene_args(sc, device=gpu)
+    radii, means2d, depths, _, _ = rd.fully_fused_projection(
+        a["means"], a["quats"], a["scales"], a["viewmats"], a["Ks"], sc.width, sc.height)
+    tw, th = math.ceil(sc.width / 16), math.ceil(sc.height / 16)
+    assert tw * th >= rd._ORDER_MIN_TILES
+    _, _, flat, offs, order = rd._bin_tiles(means2d, radii, depths, 16, tw, th, False, True, True)
+    o = offs.flatten().long().cpu()
+    lengths = torch.cat([o[1:], torch.tensor([flat.numel()])]) - o
+    order = order.long().cpu()
+    assert torch.equal(order.sort().values, torch.arange(tw * th))
+    assert (lengths[order][:-1] >= lengths[order][1:]).all()
+    # nothing visible: still a permutation
+    radii0 = torch.zeros_like(radii)
+    _, _, flat0, offs0, order0 = rd._bin_tiles(means2d, radii0, depths, 16, tw, th, False, True, True)
+    assert flat0.numel() == 0 and int(offs0.abs().sum()) == 0
+    assert torch.equal(order0.long().cpu().sort().values, torch.arange(tw * th))
+
+
 def test_isect_empty(gpu):
     rd = _rendering()
     means2d = torch.zeros(1, 10, 2, device=gpu)
