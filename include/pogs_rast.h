@@ -93,12 +93,17 @@ int pr_isect_count(int C, int N, const float *means2d, const int32_t *radii, int
  * NULL), the same table pr_isect_offsets derives from isect_ids, written here straight from the sorted
  * tile keys; tile_order[C*tile_h*tile_w] int32 (may be NULL; needs isect_offsets), the flat tile indices
  * sorted by list length, longest first -- the launch order pr_raster_fwd/bwd accept.
- * n_tiles_total = C*tile_h*tile_w when tile_order is wanted, else 0. */
+ * n_tiles_total = C*tile_h*tile_w when tile_order is wanted, else 0.
+ * n_isects_dev (may be NULL): device pointer to the true intersection count (cum_tiles + C*N - 1).  With
+ * it, n_isects is only the CAPACITY of the buffers -- a caller that does not want to wait for the count
+ * to reach the host sizes them from a guess, launches, and compares afterwards: if the true count is
+ * larger than the capacity the outputs are incomplete (never out of bounds) and the call must be repeated.
+ * Entries of flatten_ids / isect_ids past the true count are unspecified. */
 size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects, int64_t n_tiles_total);
 int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                        const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h, int64_t n_isects,
                        int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets, int32_t *tile_order,
-                       void *scratch, size_t scratch_bytes, void *stream);
+                       const int64_t *n_isects_dev, void *scratch, size_t scratch_bytes, void *stream);
 /* isect_offsets[C,tile_h,tile_w] int32: index of the first intersection of every (camera, tile). */
 int pr_isect_offsets(int64_t n_isects, const int64_t *isect_ids, int C, int tile_w, int tile_h,
                      int32_t *isect_offsets, void *stream);

@@ -176,6 +176,15 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t total, const fl
   vals[idx] = (uint32_t)idx;
 }
 
+// Number of valid intersections: the buffers hold `cap`; when the caller sized them before the true count
+// reached the host, the count is read from device memory (and clamped, so an undersized guess stays
+// memory-safe -- the host detects it and repeats the call).
+__device__ __forceinline__ int64_t true_count(int64_t cap, const int64_t *__restrict__ n_dev) {
+  if (!n_dev) return cap;
+  const int64_t n = *n_dev;
+  return n < cap ? n : cap;
+}
+
 // Emits the (camera|tile) key and the flat Gaussian index of every intersection, Gaussians in depth order.
 // Load-balanced expansion per wavefront: the 64 Gaussians of a wave own a contiguous output range
 // [start of lane 0, end of lane 63); the wave walks that range 64 outputs at a time, every lane finding the
@@ -184,7 +193,9 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t total, const fl
 __global__ void __launch_bounds__(256) isect_emit_sorted_kernel(
     int64_t total, int N, const uint32_t *__restrict__ order, const uint32_t *__restrict__ starts,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii, float ts, int tile_w, int tile_h,
-    int tile_bits, int64_t n_isects, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    int tile_bits, int64_t cap, const int64_t *__restrict__ n_dev, uint32_t *__restrict__ keys,
+    uint32_t *__restrict__ vals) {
+  const int64_t n_isects = true_count(cap, n_dev);
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   uint32_t idx = 0, start = (uint32_t)n_isects;
@@ -229,9 +240,11 @@ __global__ void __launch_bounds__(256) isect_emit_sorted_kernel(
 }
 
 // Start of every tile's range in the sorted list, from the sorted 32-bit (camera|tile) keys.
-__global__ void __launch_bounds__(256) tile_offsets_kernel(int64_t n_isects, const uint32_t *__restrict__ tkeys,
+__global__ void __launch_bounds__(256) tile_offsets_kernel(int64_t cap, const int64_t *__restrict__ n_dev,
+                                                           const uint32_t *__restrict__ tkeys,
                                                            int n_tiles_total, int tile_bits, int n_tiles,
                                                            int32_t *__restrict__ offsets) {
+  const int64_t n_isects = true_count(cap, n_dev);
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n_isects) return;
   const uint32_t mask = (1u << tile_bits) - 1u;
@@ -250,21 +263,24 @@ __global__ void __launch_bounds__(256) tile_offsets_kernel(int64_t n_isects, con
 
 // Sort keys for the launch order of the compositing kernels: the length of every tile's list.
 __global__ void __launch_bounds__(256) tile_length_kernel(int n_tiles_total, const int32_t *__restrict__ offsets,
-                                                          int64_t n_isects, uint32_t *__restrict__ keys,
+                                                          int64_t cap, const int64_t *__restrict__ n_dev,
+                                                          uint32_t *__restrict__ keys,
                                                           uint32_t *__restrict__ vals) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_tiles_total) return;
+  const int64_t n_isects = true_count(cap, n_dev);
   const int32_t hi = t + 1 < n_tiles_total ? offsets[t + 1] : (int32_t)n_isects;
   keys[t] = (uint32_t)(hi - offsets[t]);
   vals[t] = (uint32_t)t;
 }
 
-__global__ void __launch_bounds__(256) isect_ids_kernel(int64_t n_isects, const uint32_t *__restrict__ tkeys,
+__global__ void __launch_bounds__(256) isect_ids_kernel(int64_t cap, const int64_t *__restrict__ n_dev,
+                                                        const uint32_t *__restrict__ tkeys,
                                                         const int32_t *__restrict__ flatten_ids,
                                                         const float *__restrict__ depths,
                                                         int64_t *__restrict__ isect_ids) {
   int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_isects) return;
+  if (k >= true_count(cap, n_dev)) return;
   const uint32_t d = (uint32_t)__float_as_int(depths[flatten_ids[k]]);
   isect_ids[k] = ((int64_t)tkeys[k] << 32) | (int64_t)d;
 }
@@ -277,8 +293,8 @@ extern "C" size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects, in
 extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                                   const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h,
                                   int64_t n_isects, int64_t *isect_ids, int32_t *flatten_ids,
-                                  int32_t *isect_offsets, int32_t *tile_order, void *scratch,
-                                  size_t scratch_bytes, void *stream) {
+                                  int32_t *isect_offsets, int32_t *tile_order, const int64_t *n_isects_dev,
+                                  void *scratch, size_t scratch_bytes, void *stream) {
   if (C < 0 || N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0) return PR_EINVAL;
   const int64_t total = (int64_t)C * N;
   if (tile_order && !isect_offsets) return PR_EINVAL;  // the order is derived from the offsets table
@@ -291,8 +307,8 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
         if (!scratch || scratch_bytes < (size_t)n_tiles_total * 8) return PR_ESCRATCH;
         uint32_t *k = (uint32_t *)scratch;  // all lengths are zero: the identity order
         hipLaunchKernelGGL(tile_length_kernel, dim3((unsigned)((n_tiles_total + 255) / 256)), dim3(256), 0,
-                           (hipStream_t)stream, (int)n_tiles_total, isect_offsets, (int64_t)0, k,
-                           (uint32_t *)tile_order);
+                           (hipStream_t)stream, (int)n_tiles_total, isect_offsets, (int64_t)0,
+                           (const int64_t *)nullptr, k, (uint32_t *)tile_order);
         return check_launch("tile_length_kernel");
       }
     }
@@ -323,8 +339,13 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
   auto it = rocprim::make_transform_iterator((const uint32_t *)dv_out, TilesOf{tiles_per_gauss});
   tb = L.temp_bytes;
   PR_HIP(rocprim::exclusive_scan(temp, tb, it, starts, 0u, (size_t)total, rocprim::plus<uint32_t>(), st));
+  if (n_isects_dev) {
+    // capacity mode: slots past the true count keep an all-ones key and sort to the end
+    PR_HIP(hipMemsetAsync(tk_in, 0xFF, (size_t)n_isects * 4, st));
+    if (isect_offsets) PR_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)n_tiles_total * 4, st));
+  }
   hipLaunchKernelGGL(isect_emit_sorted_kernel, dim3(grid_n), dim3(256), 0, st, total, N, dv_out, starts, means2d,
-                     radii, (float)tile_size, tile_w, tile_h, tile_bits, n_isects, tk_in, tv_in);
+                     radii, (float)tile_size, tile_w, tile_h, tile_bits, n_isects, n_isects_dev, tk_in, tv_in);
   rc = check_launch("isect_emit_sorted_kernel");
   if (rc) return rc;
   tb = L.temp_bytes;
@@ -333,7 +354,7 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
                                    st));
   const unsigned grid_i = (unsigned)((n_isects + 255) / 256);
   if (isect_offsets) {
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3(grid_i), dim3(256), 0, st, n_isects, tk_out,
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3(grid_i), dim3(256), 0, st, n_isects, n_isects_dev, tk_out,
                        (int)((int64_t)C * tile_w * tile_h), tile_bits, tile_w * tile_h, isect_offsets);
     rc = check_launch("tile_offsets_kernel");
     if (rc) return rc;
@@ -342,7 +363,7 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
     uint32_t *lk_in = (uint32_t *)(base + L.lkeys_in), *lk_out = (uint32_t *)(base + L.lkeys_out);
     uint32_t *lv_in = (uint32_t *)(base + L.lvals_in);
     hipLaunchKernelGGL(tile_length_kernel, dim3((unsigned)((n_tiles_total + 255) / 256)), dim3(256), 0, st,
-                       (int)n_tiles_total, isect_offsets, n_isects, lk_in, lv_in);
+                       (int)n_tiles_total, isect_offsets, n_isects, n_isects_dev, lk_in, lv_in);
     rc = check_launch("tile_length_kernel");
     if (rc) return rc;
     tb = L.temp_bytes;
@@ -351,7 +372,7 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
                                           (unsigned)bit_length(n_isects), st));
   }
   if (isect_ids) {
-    hipLaunchKernelGGL(isect_ids_kernel, dim3(grid_i), dim3(256), 0, st, n_isects, tk_out, flatten_ids, depths,
+    hipLaunchKernelGGL(isect_ids_kernel, dim3(grid_i), dim3(256), 0, st, n_isects, n_isects_dev, tk_out, flatten_ids, depths,
                        isect_ids);
     rc = check_launch("isect_ids_kernel");
   }

@@ -187,6 +187,16 @@ class _SphericalHarmonics(torch.autograd.Function):
 
 
 _ORDER_MIN_TILES = 2048  # fewer tiles than wave slots: nothing to balance
+_count_history: Dict[tuple, tuple] = {}   # binning configuration -> intersection counts of the last two calls
+_pinned: Dict[int, Tensor] = {}
+
+
+def _pinned_count(dev: torch.device) -> Tensor:
+    """One page-locked int64 per device for the asynchronous read-back of the intersection count."""
+    t = _pinned.get(dev.index)
+    if t is None:
+        t = _pinned[dev.index] = torch.empty(1, dtype=torch.int64, pin_memory=True)
+    return t
 
 
 def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int, tile_height: int,
@@ -216,15 +226,47 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
         _call("pr_isect_count", C, N, _ptr(means2d), _ptr(radii), tile_size, tile_width, tile_height,
                                       _ptr(tiles_per_gauss), _ptr(cum), _ptr(scratch), nb, _stream())
-        n_isects = int(cum[-1].item())  # the path's one device->host read
-        isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev) if want_ids else None
-        flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
-        nb = max(lib.pr_isect_sort_scratch_bytes(C, N, n_isects, n_tiles if order is not None else 0),
-                 8 * n_tiles if order is not None else 0)
-        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-        _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(tiles_per_gauss), tile_size,
-                                          tile_width, tile_height, n_isects, _ptr(isect_ids), _ptr(flatten_ids),
-                                          _ptr(offsets), _ptr(order), _ptr(scratch), nb, _stream())
+
+        def emit(capacity, count_on_device):
+            ids = torch.empty(capacity, dtype=torch.int64, device=dev) if want_ids else None
+            flat = torch.empty(capacity, dtype=torch.int32, device=dev)
+            nb = max(lib.pr_isect_sort_scratch_bytes(C, N, capacity, n_tiles if order is not None else 0),
+                     8 * n_tiles if order is not None else 0)
+            scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+            _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(tiles_per_gauss),
+                  tile_size, tile_width, tile_height, capacity, _ptr(ids), _ptr(flat), _ptr(offsets), _ptr(order),
+                  cum[-1:].data_ptr() if count_on_device else None, _ptr(scratch), nb, _stream())
+            return ids, flat
+
+        # The intersection count sizes the lists.  Waiting for it on the host leaves the GPU idle for the
+        # round trip, so when the same configuration has produced a stable count on the previous calls
+        # (a tracking loop, repeated views) the lists are sized from that count plus a margin, the kernels
+        # read the true count from device memory, and the host compares afterwards -- by then the GPU has
+        # the sort queued.  A guess that turns out too small costs one repeated call and switches the
+        # speculation off until the count is stable again.
+        key = (dev.index, C, N, tile_size, tile_width, tile_height)
+        hist = _count_history.get(key)
+        guess = None
+        if hist is not None and hist[0] > 0 and abs(hist[1] - hist[0]) <= 0.02 * hist[0]:
+            guess = int(max(hist) * 1.03) + 1024
+        if guess is None:
+            n_isects = int(cum[-1].item())
+            isect_ids, flatten_ids = emit(n_isects, False)
+        else:
+            host = _pinned_count(dev)
+            host.copy_(cum[-1:], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            isect_ids, flatten_ids = emit(guess, True)
+            done.synchronize()
+            n_isects = int(host.item())
+            if n_isects > guess:
+                isect_ids, flatten_ids = emit(n_isects, False)
+            else:
+                flatten_ids = flatten_ids[:n_isects]
+                isect_ids = None if isect_ids is None else isect_ids[:n_isects]
+        missed = guess is not None and n_isects > guess
+        _count_history[key] = (0, n_isects) if hist is None or missed else (hist[1], n_isects)
     if want_order:
         return tiles_per_gauss, isect_ids, flatten_ids, offsets, order
     return tiles_per_gauss, isect_ids, flatten_ids, offsets

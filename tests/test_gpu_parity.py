@@ -178,6 +178,42 @@ def test_tile_order_is_a_permutation_by_descending_length(gpu):
     assert torch.equal(order0.long().cpu().sort().values, torch.arange(tw * th))
 
 
+def test_binning_with_lists_sized_from_a_guess(gpu):
+    """Third and later calls of one configuration size the lists from the previous counts and read the true
+    count on the device; results must equal the exact-size path, also when the guess is too small."""
+    rd = _rendering()
+    sc = small_scene(n=3000, w=320, h=200, seed=12, lo=0.01, hi=0.2)
+    a = scene_args(sc, device=gpu)
+    radii, means2d, depths, _, _ = rd.fully_fused_projection(
+        a["means"], a["quats"], a["scales"], a["viewmats"], a["Ks"], sc.width, sc.height)
+    tw, th = math.ceil(sc.width / 16), math.ceil(sc.height / 16)
+    rd._count_history.clear()
+    ref = rd._bin_tiles(means2d, radii, depths, 16, tw, th, True, True)
+    key = next(iter(rd._count_history))
+    assert rd._count_history[key][0] == 0                      # first call: exact path
+    rd._bin_tiles(means2d, radii, depths, 16, tw, th, True, True)
+    n = ref[2].numel()
+    assert rd._count_history[key] == (n, n)                    # stable: the next call speculates
+    got = rd._bin_tiles(means2d, radii, depths, 16, tw, th, True, True)
+    for x, y in zip(got, ref):
+        assert torch.equal(x, y)
+    assert got[2].numel() == n and got[1].numel() == n
+    # a guess that is too small: bigger radii -> more intersections than history predicts
+    radii2 = radii * 2
+    exact = rd.isect_tiles(means2d, radii2, depths, 16, tw, th)  # same key, history now stale
+    rd._count_history[key] = (n, n)
+    assert exact[1].numel() > int(n * 1.03) + 1024
+    got2 = rd._bin_tiles(means2d, radii2, depths, 16, tw, th, True, True)
+    assert torch.equal(got2[1], exact[1]) and torch.equal(got2[2], exact[2])
+    assert rd._count_history[key][0] == 0                      # speculation off until stable again
+    # a guess that is too large (fewer intersections than capacity)
+    rd._count_history[key] = (exact[1].numel(), exact[1].numel())
+    got3 = rd._bin_tiles(means2d, radii, depths, 16, tw, th, True, True)
+    for x, y in zip(got3, ref):
+        assert torch.equal(x, y)
+    rd._count_history.clear()
+
+
 def test_isect_empty(gpu):
     rd = _rendering()
     means2d = torch.zeros(1, 10, 2, device=gpu)
