@@ -79,13 +79,19 @@ int pr_sh_bwd(int C, int N, int K, int degree, const float *means, const float *
               float *v_coeffs, float *v_means, float *v_campos, void *stream);
 
 /* ---- tile binning: stands in for gsplat `isect_tiles` + `isect_offset_encode` --------------------------
- * Phase 1: tiles_per_gauss[C,N] int32 and its inclusive prefix sum cum_tiles[C*N] int64.
- * The caller reads cum_tiles[C*N-1] back to the host to learn n_isects (the only D2H of the path),
- * then calls phase 2 with buffers of that size. */
+ * Phase 1: tiles_per_gauss[C,N] int32 and its inclusive prefix sum cum_tiles[C*N] int64 (may be NULL with
+ * scratch NULL: counts only).  The caller reads cum_tiles[C*N-1] back to the host to learn n_isects (the only
+ * D2H of the path), then calls phase 2 with buffers of that size.
+ * conics[C,N,3] / opacities[C,N] (both NULL or both given) select which pairs are binned:
+ *   NULL  -- gsplat's rule: every tile the square 3-sigma bounding box of the Gaussian touches;
+ *   given -- of those, only the tiles in which the Gaussian can reach alpha >= 1/255 at some pixel centre.
+ *            The compositor ignores the other pairs pixel by pixel, so rendered values and gradients are the
+ *            same either way; the lists (and gsplat's `tiles_per_gauss`, `isect_ids`, `flatten_ids`,
+ *            `isect_offsets`) are shorter.  Phase 2 must be given the same conics/opacities. */
 size_t pr_isect_count_scratch_bytes(int C, int N);
-int pr_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size, int tile_w,
-                   int tile_h, int32_t *tiles_per_gauss, int64_t *cum_tiles, void *scratch,
-                   size_t scratch_bytes, void *stream);
+int pr_isect_count(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
+                   const float *opacities, int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss,
+                   int64_t *cum_tiles, void *scratch, size_t scratch_bytes, void *stream);
 /* Phase 2: key = cam<<(32+tile_bits) | tile<<32 | float_bits(depth), value = flat index, in stable
  * ascending key order (ties by ascending flat index).  tiles_per_gauss is phase 1's output.
  * Out: flatten_ids[n_isects] int32; isect_ids[n_isects] int64 (may be NULL: the 64-bit keys are only
@@ -101,7 +107,7 @@ int pr_isect_count(int C, int N, const float *means2d, const int32_t *radii, int
  * Entries of flatten_ids / isect_ids past the true count are unspecified. */
 size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects, int64_t n_tiles_total);
 int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
-                       const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h, int64_t n_isects,
+                       const float *conics, const float *opacities, const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h, int64_t n_isects,
                        int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets, int32_t *tile_order,
                        const int64_t *n_isects_dev, void *scratch, size_t scratch_bytes, void *stream);
 /* isect_offsets[C,tile_h,tile_w] int32: index of the first intersection of every (camera, tile). */

@@ -103,6 +103,35 @@ __device__ __forceinline__ void atomic_add_noret(float *addr, float v) {
   asm volatile("global_atomic_add_f32 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
 }
 
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;  // smallest alpha the compositor lets contribute
+
+// Exact footprint test of one Gaussian against a pixel-centre rectangle [rx0,rx1] x [ry0,ry1]: the
+// minimum of the (convex) quadratic form sigma over the rectangle bounds the largest alpha any pixel of
+// the region can see.  If even that is below 1/255 the Gaussian cannot contribute to this region (the
+// square 3-sigma bounding box that built the tile lists is far looser for elongated or faint Gaussians).
+// Conservative by a margin of 1e-3 in the exponent; non-positive-definite conics are always kept.
+__device__ __forceinline__ bool touches_region(float gx, float gy, float o, float a, float b, float c, float rx0,
+                                               float ry0, float rx1, float ry1) {
+  if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return true;
+  const float xl = rx0 - gx, xr = rx1 - gx, yl = ry0 - gy, yr = ry1 - gy;
+  const float X = fminf(fmaxf(0.f, xl), xr), Y = fminf(fmaxf(0.f, yl), yr);  // nearest rectangle point per axis
+  float smin = 0.f;
+  if (X != 0.f || Y != 0.f) {
+    float s1 = 3.0e38f, s2 = 3.0e38f;
+    if (X != 0.f) {
+      const float uy = fminf(fmaxf(-b * X / c, yl), yr);
+      s1 = 0.5f * (a * X * X + c * uy * uy) + b * X * uy;
+    }
+    if (Y != 0.f) {
+      const float ux = fminf(fmaxf(-b * Y / a, xl), xr);
+      s2 = 0.5f * (a * ux * ux + c * Y * Y) + b * ux * Y;
+    }
+    smin = fmaxf(fminf(s1, s2), 0.f);
+  }
+  return o * __builtin_amdgcn_exp2f(1e-3f - smin * LOG2E) >= ALPHA_MIN;
+}
+
 __device__ __forceinline__ float wave_sum_all(float v) {
   v = wave_sum_to_lane63(v);
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));

@@ -59,6 +59,135 @@ __global__ void __launch_bounds__(256) isect_offsets_kernel(int64_t n_isects, co
     for (int t = cur + 1; t < n_tiles_total; ++t) offsets[t] = (int32_t)n_isects;
 }
 
+// ---- footprint-tested ("tight") binning --------------------------------------------------------------
+// The reference bins a Gaussian into every tile its square 3-sigma bounding box touches.  About half of
+// those (Gaussian, tile) pairs cannot reach alpha >= 1/255 at any pixel of the tile (elongated or faint
+// Gaussians, box corners); the compositor skips them pixel by pixel, so dropping them at binning time leaves
+// every rendered value unchanged while the sort, the lists and the staging loads shrink.  The test is the
+// one the compositor applies per wave region, here against the whole tile; count and emission call the SAME
+// out-of-line function so that they cannot disagree by a rounding.
+__device__ __noinline__ bool touches_tile(float gx, float gy, float o, float a, float b, float c, float rx0,
+                                          float ry0, float rx1, float ry1) {
+  return touches_region(gx, gy, o, a, b, c, rx0, ry0, rx1, ry1);
+}
+
+struct WaveCandidates {  // per lane: one Gaussian and its bounding-box tiles
+  float gx, gy, o, a, b, c;
+  int x0, y0, w, cnt, cstart, total;
+};
+
+// Loads lane's Gaussian `idx` (or nothing when !valid) and scans the bounding-box tile counts over the wave.
+__device__ __forceinline__ WaveCandidates load_candidates(bool valid, int64_t idx, const float *__restrict__ means2d,
+                                                          const int32_t *__restrict__ radii,
+                                                          const float *__restrict__ conics,
+                                                          const float *__restrict__ opacities, float ts, int tile_w,
+                                                          int tile_h, int lane) {
+  WaveCandidates g = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0, 1, 0, 0, 0};
+  if (valid) {
+    const int rad = radii[idx];
+    if (rad > 0) {
+      g.gx = means2d[2 * idx];
+      g.gy = means2d[2 * idx + 1];
+      TileRect t = tile_rect(g.gx, g.gy, rad, ts, tile_w, tile_h);
+      const int n = (t.x1 - t.x0) * (t.y1 - t.y0);
+      if (n > 0) {
+        g.x0 = t.x0;
+        g.y0 = t.y0;
+        g.w = t.x1 - t.x0;
+        g.cnt = n;
+        g.a = conics[3 * idx];
+        g.b = conics[3 * idx + 1];
+        g.c = conics[3 * idx + 2];
+        g.o = opacities[idx];
+      }
+    }
+  }
+  int incl = g.cnt;  // inclusive scan over the 64 lanes
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  g.cstart = incl - g.cnt;
+  g.total = __shfl(incl, 63);
+  return g;
+}
+
+// Candidate number c of the wave -> which lane's Gaussian (j) and which tile; returns whether it passes.
+__device__ __forceinline__ bool test_candidate(const WaveCandidates &g, int c, float ts, int &j, int &tile_x,
+                                               int &tile_y) {
+  j = 0;  // last lane whose first candidate is <= c
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1) {
+    const int sc = __shfl(g.cstart, (j + step) & 63);
+    if (j + step < 64 && sc <= c) j += step;
+  }
+  const int t = c - __shfl(g.cstart, j);
+  const int wj = __shfl(g.w, j);
+  const int ty = t / wj, tx = t - ty * wj;
+  tile_x = __shfl(g.x0, j) + tx;
+  tile_y = __shfl(g.y0, j) + ty;
+  const float gx = __shfl(g.gx, j), gy = __shfl(g.gy, j), o = __shfl(g.o, j);
+  const float a = __shfl(g.a, j), b = __shfl(g.b, j), cc = __shfl(g.c, j);
+  if (c >= g.total) return false;
+  const float rx0 = (float)tile_x * ts + 0.5f, ry0 = (float)tile_y * ts + 0.5f;
+  return touches_tile(gx, gy, o, a, b, cc, rx0, ry0, rx0 + ts - 1.f, ry0 + ts - 1.f);
+}
+
+__global__ void __launch_bounds__(256) isect_count_tight_kernel(
+    int64_t total, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+    const float *__restrict__ conics, const float *__restrict__ opacities, float ts, int tile_w, int tile_h,
+    int32_t *__restrict__ tiles_per_gauss) {
+  __shared__ int counts[256];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int *mine = counts + (threadIdx.x & ~63);
+  mine[lane] = 0;
+  const WaveCandidates g = load_candidates(idx < total, idx, means2d, radii, conics, opacities, ts, tile_w, tile_h, lane);
+  for (int c0 = 0; c0 < g.total; c0 += 64) {
+    int j, tx, ty;
+    if (test_candidate(g, c0 + lane, ts, j, tx, ty)) atomicAdd(&mine[j], 1);
+  }
+  if (idx < total) tiles_per_gauss[idx] = mine[lane];
+}
+
+// Footprint-tested emission: like isect_emit_sorted_kernel, but the wave enumerates the bounding-box tiles
+// of its 64 Gaussians as candidates and writes only those that pass, compacted in candidate order.
+__global__ void __launch_bounds__(256) isect_emit_tight_kernel(
+    int64_t total, int N, const uint32_t *__restrict__ order, const uint32_t *__restrict__ starts,
+    const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
+    const float *__restrict__ opacities, const int32_t *__restrict__ tiles_per_gauss, float ts, int tile_w,
+    int tile_h, int tile_bits, int64_t cap, const int64_t *__restrict__ n_dev, uint32_t *__restrict__ keys,
+    uint32_t *__restrict__ vals) {
+  const int64_t n_isects = n_dev ? (*n_dev < cap ? *n_dev : cap) : cap;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  uint32_t idx = 0, start = 0;
+  bool valid = false;
+  if (r < total) {
+    idx = order[r];
+    start = starts[r];
+    valid = tiles_per_gauss[idx] > 0;
+  }
+  const WaveCandidates g = load_candidates(valid, (int64_t)idx, means2d, radii, conics, opacities, ts, tile_w, tile_h, lane);
+  const uint32_t hi = (idx / (uint32_t)N) << tile_bits;
+  int64_t pos = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)start, 0);  // lane 0 is always in range
+  for (int c0 = 0; c0 < g.total; c0 += 64) {
+    int j, tx, ty;
+    const bool pass = test_candidate(g, c0 + lane, ts, j, tx, ty);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+    const uint32_t hj = (uint32_t)__shfl((int)hi, j), ij = (uint32_t)__shfl((int)idx, j);
+    if (pass) {
+      const int64_t k = pos + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (k < n_isects) {
+        keys[k] = hj | (uint32_t)(ty * tile_w + tx);
+        vals[k] = ij;
+      }
+    }
+    pos += __builtin_popcountll(m);
+  }
+}
+
 struct ToI64 {
   __device__ __host__ int64_t operator()(int32_t v) const { return (int64_t)v; }
 };
@@ -87,18 +216,28 @@ extern "C" size_t pr_isect_count_scratch_bytes(int C, int N) {
   return align256(bytes) + 256;
 }
 
-extern "C" int pr_isect_count(int C, int N, const float *means2d, const int32_t *radii, int tile_size, int tile_w,
-                              int tile_h, int32_t *tiles_per_gauss, int64_t *cum_tiles, void *scratch,
-                              size_t scratch_bytes, void *stream) {
+extern "C" int pr_isect_count(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
+                              const float *opacities, int tile_size, int tile_w, int tile_h,
+                              int32_t *tiles_per_gauss, int64_t *cum_tiles, void *scratch, size_t scratch_bytes,
+                              void *stream) {
   if (C < 0 || N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return PR_EINVAL;
   int64_t total = (int64_t)C * N;
   if (total == 0) return PR_OK;
-  if (!means2d || !radii || !tiles_per_gauss || !cum_tiles || !scratch) return PR_EINVAL;
+  if (!means2d || !radii || !tiles_per_gauss) return PR_EINVAL;
+  if ((conics == nullptr) != (opacities == nullptr)) return PR_EINVAL;
+  if (cum_tiles && !scratch) return PR_EINVAL;
   unsigned grid = (unsigned)((total + 255) / 256);
-  hipLaunchKernelGGL(isect_count_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, total, means2d, radii,
-                     (float)tile_size, tile_w, tile_h, tiles_per_gauss);
-  int rc = check_launch("isect_count_kernel");
-  if (rc) return rc;
+  int rc;
+  if (conics) {
+    hipLaunchKernelGGL(isect_count_tight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, total, means2d,
+                       radii, conics, opacities, (float)tile_size, tile_w, tile_h, tiles_per_gauss);
+    rc = check_launch("isect_count_tight_kernel");
+  } else {
+    hipLaunchKernelGGL(isect_count_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, total, means2d, radii,
+                       (float)tile_size, tile_w, tile_h, tiles_per_gauss);
+    rc = check_launch("isect_count_kernel");
+  }
+  if (rc || !cum_tiles) return rc;
   size_t need = 0;
   auto in = rocprim::make_transform_iterator((const int32_t *)tiles_per_gauss, ToI64());
   PR_HIP(rocprim::inclusive_scan(nullptr, need, in, cum_tiles, (size_t)total, rocprim::plus<int64_t>(),
@@ -291,13 +430,14 @@ extern "C" size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects, in
 }
 
 extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
-                                  const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h,
+                                  const float *conics, const float *opacities, const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h,
                                   int64_t n_isects, int64_t *isect_ids, int32_t *flatten_ids,
                                   int32_t *isect_offsets, int32_t *tile_order, const int64_t *n_isects_dev,
                                   void *scratch, size_t scratch_bytes, void *stream) {
   if (C < 0 || N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0) return PR_EINVAL;
   const int64_t total = (int64_t)C * N;
   if (tile_order && !isect_offsets) return PR_EINVAL;  // the order is derived from the offsets table
+  if ((conics == nullptr) != (opacities == nullptr)) return PR_EINVAL;
   const int64_t n_tiles_total = (int64_t)C * tile_w * tile_h;
   if (n_tiles_total > (int64_t)2147483647) return PR_EUNSUPPORTED;
   if (total == 0 || n_isects == 0) {
@@ -344,9 +484,14 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
     PR_HIP(hipMemsetAsync(tk_in, 0xFF, (size_t)n_isects * 4, st));
     if (isect_offsets) PR_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)n_tiles_total * 4, st));
   }
-  hipLaunchKernelGGL(isect_emit_sorted_kernel, dim3(grid_n), dim3(256), 0, st, total, N, dv_out, starts, means2d,
-                     radii, (float)tile_size, tile_w, tile_h, tile_bits, n_isects, n_isects_dev, tk_in, tv_in);
-  rc = check_launch("isect_emit_sorted_kernel");
+  if (conics)
+    hipLaunchKernelGGL(isect_emit_tight_kernel, dim3(grid_n), dim3(256), 0, st, total, N, dv_out, starts, means2d,
+                       radii, conics, opacities, tiles_per_gauss, (float)tile_size, tile_w, tile_h, tile_bits,
+                       n_isects, n_isects_dev, tk_in, tv_in);
+  else
+    hipLaunchKernelGGL(isect_emit_sorted_kernel, dim3(grid_n), dim3(256), 0, st, total, N, dv_out, starts, means2d,
+                       radii, (float)tile_size, tile_w, tile_h, tile_bits, n_isects, n_isects_dev, tk_in, tv_in);
+  rc = check_launch("isect_emit_kernel");
   if (rc) return rc;
   tb = L.temp_bytes;
   PR_HIP(rocprim::radix_sort_pairs<SortConfig>(temp, tb, (const uint32_t *)tk_in, tk_out, (const uint32_t *)tv_in,

@@ -200,14 +200,21 @@ def _pinned_count(dev: torch.device) -> Tensor:
 
 
 def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int, tile_height: int,
-               want_ids: bool, want_offsets: bool, want_order: bool = False):
+               want_ids: bool, want_offsets: bool, want_order: bool = False, conics: Optional[Tensor] = None,
+               opacities: Optional[Tensor] = None):
     """Tile binning: -> tiles_per_gauss [C,N] int32, isect_ids [I] int64 or None, flatten_ids [I] int32,
     isect_offsets [C,th,tw] int32 or None[, tile_order [C*th*tw] int32 or None when ``want_order``: tiles
-    sorted by list length, longest first (None below ``_ORDER_MIN_TILES`` tiles)]."""
+    sorted by list length, longest first (None below ``_ORDER_MIN_TILES`` tiles)].
+
+    With ``conics`` [C,N,3] and ``opacities`` [C,N] only the (Gaussian, tile) pairs that can reach
+    alpha >= 1/255 somewhere in the tile are binned (the render path); without them, gsplat's rule (every tile
+    under the 3-sigma bounding box)."""
     lib = _lib.load()
     C, N = radii.shape
     dev = means2d.device
     means2d, radii, depths = means2d.detach().contiguous(), radii.contiguous(), depths.detach().contiguous()
+    if conics is not None:
+        conics, opacities = conics.detach().contiguous(), opacities.detach().contiguous()
     tiles_per_gauss = torch.empty(C, N, dtype=torch.int32, device=dev)
     offsets = torch.empty(C, tile_height, tile_width, dtype=torch.int32, device=dev) if want_offsets else None
     n_tiles = C * tile_height * tile_width
@@ -224,8 +231,8 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
     with torch.cuda.device(dev):
         nb = lib.pr_isect_count_scratch_bytes(C, N)
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-        _call("pr_isect_count", C, N, _ptr(means2d), _ptr(radii), tile_size, tile_width, tile_height,
-                                      _ptr(tiles_per_gauss), _ptr(cum), _ptr(scratch), nb, _stream())
+        _call("pr_isect_count", C, N, _ptr(means2d), _ptr(radii), _ptr(conics), _ptr(opacities), tile_size,
+              tile_width, tile_height, _ptr(tiles_per_gauss), _ptr(cum), _ptr(scratch), nb, _stream())
 
         def emit(capacity, count_on_device):
             ids = torch.empty(capacity, dtype=torch.int64, device=dev) if want_ids else None
@@ -233,8 +240,8 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
             nb = max(lib.pr_isect_sort_scratch_bytes(C, N, capacity, n_tiles if order is not None else 0),
                      8 * n_tiles if order is not None else 0)
             scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-            _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(tiles_per_gauss),
-                  tile_size, tile_width, tile_height, capacity, _ptr(ids), _ptr(flat), _ptr(offsets), _ptr(order),
+            _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(conics),
+                  _ptr(opacities), _ptr(tiles_per_gauss), tile_size, tile_width, tile_height, capacity, _ptr(ids), _ptr(flat), _ptr(offsets), _ptr(order),
                   cum[-1:].data_ptr() if count_on_device else None, _ptr(scratch), nb, _stream())
             return ids, flat
 
@@ -244,7 +251,7 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
         # read the true count from device memory, and the host compares afterwards -- by then the GPU has
         # the sort queued.  A guess that turns out too small costs one repeated call and switches the
         # speculation off until the count is stable again.
-        key = (dev.index, C, N, tile_size, tile_width, tile_height)
+        key = (dev.index, C, N, tile_size, tile_width, tile_height, conics is not None)
         hist = _count_history.get(key)
         guess = None
         if hist is not None and hist[0] > 0 and abs(hist[1] - hist[0]) <= 0.02 * hist[0]:
@@ -295,20 +302,27 @@ def _isect_ids_from_lists(isect_offsets: Tensor, flatten_ids: Tensor, depths: Te
 
 
 class RenderMeta(dict):
-    """The ``meta`` dict of ``rasterization``.  Every gsplat key is present; ``isect_ids`` -- which nothing
-    on the render path reads -- is only materialised when it is first asked for."""
+    """The ``meta`` dict of ``rasterization``.  Every gsplat key is present.  The binning tables gsplat
+    reports (``tiles_per_gauss``, ``isect_ids``, ``flatten_ids``, ``isect_offsets``: every tile under each
+    Gaussian's 3-sigma bounding box) are not what the compositor here walks -- it bins only the pairs that can
+    contribute -- and nothing on the render path reads them, so they are computed when first asked for."""
 
-    _LAZY = "isect_ids"
+    def __init__(self, values, lazy):
+        super().__init__(values)
+        self._lazy = lazy      # one thunk producing all the lazy entries at once
+        for k in lazy.keys:
+            dict.__setitem__(self, k, None)
 
     def _resolve(self):
-        v = dict.__getitem__(self, self._LAZY)
-        if callable(v):
-            v = v()
-            dict.__setitem__(self, self._LAZY, v)
-        return v
+        if self._lazy is not None:
+            thunk, self._lazy = self._lazy, None
+            for k, v in thunk().items():
+                dict.__setitem__(self, k, v)
 
     def __getitem__(self, key):
-        return self._resolve() if key == self._LAZY else dict.__getitem__(self, key)
+        if self._lazy is not None and key in self._lazy.keys:
+            self._resolve()
+        return dict.__getitem__(self, key)
 
     def get(self, key, default=None):
         return self[key] if key in self else default
@@ -324,6 +338,19 @@ class RenderMeta(dict):
     def copy(self):
         self._resolve()
         return dict(self)
+
+
+class _ReferenceBinning:
+    """Thunk for RenderMeta: gsplat's binning tables of one render."""
+
+    keys = ("tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets")
+
+    def __init__(self, means2d, radii, depths, tile_size, tile_width, tile_height):
+        self.args = (means2d.detach(), radii, depths.detach(), tile_size, tile_width, tile_height)
+
+    def __call__(self):
+        tpg, ids, flat, offs = _bin_tiles(*self.args, True, True)
+        return {"tiles_per_gauss": tpg, "isect_ids": ids, "flatten_ids": flat, "isect_offsets": offs}
 
 
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
@@ -617,8 +644,11 @@ def rasterization(
 
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
-    tiles_per_gauss, _, flatten_ids, isect_offsets, tile_order = _bin_tiles(
-        means2d, radii, depths, tile_size, tile_width, tile_height, False, True, True)
+    opac = opac.contiguous()
+    # compositor lists: only the (Gaussian, tile) pairs that can contribute
+    _, _, flatten_ids, isect_offsets, tile_order = _bin_tiles(
+        means2d, radii, depths, tile_size, tile_width, tile_height, False, True, True, conics=conics,
+        opacities=opac)
 
     # expected depth (ED): the depth channel is divided by max(alpha, 1e-10) inside the kernels
     ed_channel = cols.shape[-1] - 1 if render_mode in ("ED", "RGB+ED") else -1
@@ -629,9 +659,7 @@ def rasterization(
     meta = RenderMeta({
         "camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths,
         "conics": conics, "opacities": opac, "tile_width": tile_width, "tile_height": tile_height,
-        "tiles_per_gauss": tiles_per_gauss,
-        "isect_ids": lambda: _isect_ids_from_lists(isect_offsets, flatten_ids, depths), "flatten_ids": flatten_ids,
-        "isect_offsets": isect_offsets, "width": width, "height": height, "tile_size": tile_size,
-        "n_cameras": C,
-    })
+        "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
+        "n_composited_isects": flatten_ids.numel(),
+    }, _ReferenceBinning(means2d, radii, depths, tile_size, tile_width, tile_height))
     return render_colors, render_alphas, meta

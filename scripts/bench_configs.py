@@ -56,7 +56,7 @@ def training_shape(n, w, h, f, ts=16, iters=10, warmup=3):
                                              K, w, h, sh_degree=3, render_mode="RGB+ED", packed=False, absgrad=True,
                                              tile_size=ts, features=p["f"])
         torch.autograd.backward([r, a], [vc, va])
-        info["I"] = meta["flatten_ids"].numel()
+        info["I"] = meta["n_composited_isects"]
 
     ms = timed(step, iters, warmup)
     return {"gaussians": n, "size": [w, h], "channels": D, "tile": ts, "n_isects": info["I"], "ms_fwd_bwd": ms,

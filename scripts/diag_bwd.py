@@ -23,6 +23,6 @@ def step():
 step(); torch.cuda.synchronize(); lib.pr_diag_read(out, 1)
 meta = step(); torch.cuda.synchronize(); lib.pr_diag_read(out, 1)
 it, npx, nslots, nrows, nhalf, nlanes = [int(x) for x in out[:6]]
-print(json.dumps({"cfg": sys.argv[1:], "I": meta["flatten_ids"].numel(), "contributing_iters": it, "active_px_per_iter": npx / it,
+print(json.dumps({"cfg": sys.argv[1:], "I": meta["n_composited_isects"], "contributing_iters": it, "active_px_per_iter": npx / it,
                   "active_slots_per_iter": nslots / it, "active_rows_per_iter": nrows / it, "active_halves_per_iter": nhalf / it,
                   "active_lanes_per_iter": nlanes / it}))

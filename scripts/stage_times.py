@@ -24,4 +24,4 @@ torch.cuda.synchronize()
 import time; t0 = time.perf_counter()
 for _ in range(10): step()
 torch.cuda.synchronize(); el = (time.perf_counter() - t0) / 10 * 1e3
-print(json.dumps({"cfg": sys.argv[1:], "I": meta["flatten_ids"].numel(), "ms": round(el, 3), "stages": {k: round(v[1] / 10, 4) for k, v in sorted(t.summary().items(), key=lambda kv: -kv[1][1])}}))
+print(json.dumps({"cfg": sys.argv[1:], "I": meta["n_composited_isects"], "ms": round(el, 3), "stages": {k: round(v[1] / 10, 4) for k, v in sorted(t.summary().items(), key=lambda kv: -kv[1][1])}}))

@@ -214,6 +214,48 @@ def test_binning_with_lists_sized_from_a_guess(gpu):
     rd._count_history.clear()
 
 
+@pytest.mark.parametrize("tile_size", [8, 16])
+def test_footprint_tested_lists_drop_only_pairs_that_cannot_contribute(gpu, tile_size):
+    """The compositor's lists are a subsequence of gsplat's per-tile lists, and every dropped (Gaussian, tile)
+    pair stays below alpha = 1/255 at every pixel centre of the tile."""
+    rd = _rendering()
+    sc = small_scene(n=1200, w=160, h=96, views=2, seed=4, lo=0.01, hi=0.35)
+    a = scene_args(sc, device=gpu)
+    radii, means2d, depths, conics, _ = rd.fully_fused_projection(
+        a["means"], a["quats"], a["scales"], a["viewmats"], a["Ks"], sc.width, sc.height)
+    opac = a["opacities"][None].expand(2, -1).contiguous()
+    tw, th = math.ceil(sc.width / tile_size), math.ceil(sc.height / tile_size)
+    _, _, flat_r, offs_r = rd._bin_tiles(means2d, radii, depths, tile_size, tw, th, False, True)
+    tpg_t, _, flat_t, offs_t = rd._bin_tiles(means2d, radii, depths, tile_size, tw, th, False, True,
+                                             conics=conics, opacities=opac)
+    assert 0 < flat_t.numel() < 0.8 * flat_r.numel()
+    assert int(tpg_t.sum()) == flat_t.numel()
+    flat_r, flat_t = flat_r.cpu().tolist(), flat_t.cpu().tolist()
+    o_r = offs_r.flatten().cpu().tolist() + [len(flat_r)]
+    o_t = offs_t.flatten().cpu().tolist() + [len(flat_t)]
+    m2, cn, op = means2d.double().cpu().view(-1, 2), conics.double().cpu().view(-1, 3), opac.double().cpu().view(-1)
+    dropped = 0
+    for t in range(2 * tw * th):
+        ref, tight = flat_r[o_r[t]:o_r[t + 1]], flat_t[o_t[t]:o_t[t + 1]]
+        it = iter(ref)
+        assert all(g in it for g in tight), "not a subsequence of the reference list"
+        gone = sorted(set(ref) - set(tight))
+        if not gone:
+            continue
+        dropped += len(gone)
+        tile = t % (tw * th)
+        ys = torch.arange((tile // tw) * tile_size, min((tile // tw + 1) * tile_size, sc.height)).double() + 0.5
+        xs = torch.arange((tile % tw) * tile_size, min((tile % tw + 1) * tile_size, sc.width)).double() + 0.5
+        g = torch.tensor(gone)
+        dx = xs[None, None, :] - m2[g, 0][:, None, None]
+        dy = ys[None, :, None] - m2[g, 1][:, None, None]
+        sigma = (0.5 * (cn[g, 0][:, None, None] * dx * dx + cn[g, 2][:, None, None] * dy * dy)
+                 + cn[g, 1][:, None, None] * dx * dy)
+        alpha = op[g][:, None, None] * torch.exp(-sigma)
+        assert alpha.amax().item() < 1.0 / 255.0
+    assert dropped > 0
+
+
 def test_isect_empty(gpu):
     rd = _rendering()
     means2d = torch.zeros(1, 10, 2, device=gpu)
