@@ -114,11 +114,30 @@ int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii,
 int pr_isect_offsets(int64_t n_isects, const int64_t *isect_ids, int C, int tile_w, int tile_h,
                      int32_t *isect_offsets, void *stream);
 
+/* The D composited channels may be supplied as up to three tensors laid side by side in channel order instead
+ * of one [C,N,D] tensor (e.g. SH colours [C,N,3] | per-Gaussian features [N,F] | depths [C,N]): segment i holds
+ * `width` channels in rows of pitch `ld` floats; shared != 0 means one row per Gaussian for all cameras (row
+ * index n), otherwise the row index is c*N + n.  Widths add up to D.  No gsplat counterpart (gsplat
+ * concatenates into one tensor, pogs/pogs.py passes the result). */
+typedef struct {
+  const float *ptr;
+  int width, ld, shared;
+} pr_color_segment;
+/* Gradient destinations in the same layout; ptr NULL = no gradient wanted for that segment.  A shared segment
+ * accumulates the contributions of all cameras.  Zero-filled by the caller. */
+typedef struct {
+  float *ptr;
+  int width, ld, shared;
+} pr_grad_segment;
+
 /* ---- compositing: stands in for gsplat `rasterize_to_pixels` forward/backward --------------------------
  * means2d[C,N,2] conics[C,N,3] colors[C,N,D] opacities[C,N] backgrounds[C,D] (may be NULL).
  * ed_channel >= 0 names the channel that holds depth and is to be output as EXPECTED depth, i.e. divided by
  * max(alpha, 1e-10) (what gsplat's `rasterization` does after the kernel for render modes ED / RGB+ED);
  * -1 = none.
+ * segments/n_segments (NULL/0 = use `colors`): the channels gathered from up to three tensors, see
+ * pr_color_segment; `colors` may then be NULL.  pr_raster_bwd scatters the colour gradients into v_segments
+ * (same count and widths) instead of v_colors.
  * tile_order (may be NULL) is a permutation of the C*tile_h*tile_w flat tile indices: the order in which
  * wavefronts pick tiles up.  Results do not depend on it; listing the longest tiles first shortens the tail
  * of the launch.
@@ -128,7 +147,7 @@ int pr_raster_fwd(int C, int N, int D, const float *means2d, const float *conics
                   const float *opacities, const float *backgrounds, int width, int height, int tile_size,
                   int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
                   const int32_t *flatten_ids, int64_t n_isects, int ed_channel, float *render_colors, float *render_alphas,
-                  int32_t *last_ids, void *stream);
+                  int32_t *last_ids, const pr_color_segment *segments, int n_segments, void *stream);
 /* v_render_colors[C,H,W,D], v_render_alphas[C,H,W]; render_colors (the forward output) is read only when
  * ed_channel >= 0 and may be NULL otherwise.
  * Out, all zero-filled by the caller and accumulated into with float atomics:
@@ -142,6 +161,7 @@ int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics
                   const int32_t *flatten_ids, int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
                   const float *render_colors, int ed_channel, const float *v_render_colors,
                   const float *v_render_alphas, int absgrad, int geom_grad, float *v_geom, float *v_colors,
+                  const pr_color_segment *segments, const pr_grad_segment *v_segments, int n_segments,
                   void *stream);
 
 /* ---- rigid-group transform of the Gaussian model (the tracker's per-iteration pose update) ----

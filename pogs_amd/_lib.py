@@ -34,12 +34,26 @@ SIGNATURES = {
                                    _P, _P, _P, c_size_t, _P]),
     "pr_isect_offsets": (c_int, [c_int64, _P, c_int, c_int, c_int, _P, _P]),
     "pr_raster_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
-                              c_int64, c_int, _P, _P, _P, _P]),
+                              c_int64, c_int, _P, _P, _P, _P, c_int, _P]),
     "pr_raster_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
-                              c_int64, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P]),
+                              c_int64, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
     "pr_rigid_fwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pr_rigid_bwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
+
+
+
+class Segment(ctypes.Structure):
+    """pr_color_segment / pr_grad_segment (same layout): one of up to three tensors that together supply the
+    composited channels."""
+    _fields_ = [("ptr", ctypes.c_void_p), ("width", c_int), ("ld", c_int), ("shared", c_int)]
+
+
+def segment_array(items):
+    """[(data_ptr or None, width, ld, shared)] -> (ctypes array kept alive by the caller, void pointer)."""
+    arr = (Segment * len(items))(*[Segment(p, w, ld, int(sh)) for p, w, ld, sh in items])
+    return arr, ctypes.cast(arr, ctypes.c_void_p)
+
 
 _lib = None
 

@@ -27,12 +27,12 @@ __device__ unsigned long long g_diag[8];
 template <int TS, int PPL, int CD, bool GEOM>
 __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
+    const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
     const int32_t *__restrict__ tile_order, const int32_t *__restrict__ flatten_ids, int n_isects, const float *__restrict__ render_alphas,
     const int32_t *__restrict__ last_ids, const float *__restrict__ render_colors, int ed_channel,
     const float *__restrict__ v_render_colors, const float *__restrict__ v_render_alphas, int absgrad,
-    float *__restrict__ v_geom, float *__restrict__ v_colors) {
+    float *__restrict__ v_geom, const GradSegs gs) {
   using Rg = Region<TS, PPL>;
   constexpr int ROW = color_row(CD);
   constexpr int CDP = round4(CD);
@@ -133,6 +133,23 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
     gscale = (gi == 0 || gi == 1) ? -LN2 : (gi == 2 || gi == 4) ? 0.5f : (gi == 6 || gi == 7) ? LN2 : 1.f;
   }
 
+  // Where this lane's colour values go: value k = k0 + lane is channel ch_off + k of some gradient segment;
+  // its address for Gaussian gid is gcol + row * gld, row = gid (per camera) or gid - cam*N (shared).
+  constexpr int NK = (NV + WAVE - 1) / WAVE;
+  float *gcol[NK];
+  int gld[NK];
+  bool gshared[NK];
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+    const int ch = ch_off + i * WAVE + lane;
+    const int sgm = ch >= gs.begin[2] ? 2 : ch >= gs.begin[1] ? 1 : 0;
+    float *p = gs.ptr[sgm];
+    gcol[i] = (p && i * WAVE + lane < nch) ? p + (ch - gs.begin[sgm]) : nullptr;
+    gld[i] = gs.ld[sgm];
+    gshared[i] = gs.shared[sgm] != 0;
+  }
+  const int cam_first = cam * N;
+
   const float rx0 = (float)(tx * TS) + 0.5f, ry0 = (float)(ty * TS + sub * Rg::RH) + 0.5f;
   const float rx1 = (float)min(tx * TS + TS, width) - 0.5f;
   const float ry1 = (float)min(ty * TS + sub * Rg::RH + Rg::RH, height) - 0.5f;
@@ -140,7 +157,7 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
     const int first = max(range_lo, bend - WAVE);
     const int count = bend - first;
     unsigned long long todo = stage_batch<CD>(L, lane, first, count, flatten_ids, means2d, conics, opacities,
-                                              colors, D, ch_off, rx0, ry0, rx1, ry1);
+                                              cs, N, D, ch_off, rx0, ry0, rx1, ry1);
     while (todo) {
       const int t = 63 - __builtin_clzll(todo);
       todo &= ~(1ull << t);
@@ -278,7 +295,8 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
           const float v = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w)) +
                           (((p2.x + p2.y) + (p2.z + p2.w)) + ((p3.x + p3.y) + (p3.z + p3.w)));
           if (k < CDP) {
-            if (v_colors && k < nch) atomic_add_noret(v_colors + (int64_t)gid * D + ch_off + k, v);
+            float *dst = gcol[k0 / WAVE];
+            if (dst) atomic_add_noret(dst + (int64_t)(gshared[k0 / WAVE] ? gid - cam_first : gid) * gld[k0 / WAVE], v);
           } else if (GEOM) {
             const int gi = k - CDP;
             const float sc = (k0 == 0) ? gscale
@@ -294,19 +312,19 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
 }
 
 template <int TS, int PPL, int CD, bool GEOM>
-static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const float *colors,
+static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const ColorSegs &cs,
                       const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
                       const int32_t *isect_offsets, const int32_t *tile_order, const int32_t *flatten_ids,
                       int64_t n_isects,
                       const float *render_alphas, const int32_t *last_ids, const float *render_colors,
                       int ed_channel, const float *v_render_colors, const float *v_render_alphas, int absgrad,
-                      float *v_geom, float *v_colors, hipStream_t stream) {
+                      float *v_geom, const GradSegs &gs, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
   const unsigned grid = (unsigned)((n_regions + WPB - 1) / WPB);
   hipLaunchKernelGGL((raster_bwd_kernel<TS, PPL, CD, GEOM>), dim3(grid), dim3(64 * WPB), 0, stream, (int)n_regions, N, D,
-                     ch_off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h,
+                     ch_off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h,
                      isect_offsets, tile_order, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel,
-                     v_render_colors, v_render_alphas, absgrad, v_geom, v_colors);
+                     v_render_colors, v_render_alphas, absgrad, v_geom, gs);
   return check_launch("raster_bwd_kernel");
 }
 
@@ -365,9 +383,9 @@ using namespace pr;
 extern "C" int pr_max_channels(void) { return 100; }
 
 #define BWD_ARGS                                                                                                     \
-  C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,       \
+  C, N, D, off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,           \
       tile_order, flatten_ids, n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors,        \
-      v_render_alphas, absgrad, v_geom, v_colors, (hipStream_t)stream
+      v_render_alphas, absgrad, v_geom, gs, (hipStream_t)stream
 #define BWD_CASE(TS, PPL, CDV)                                      \
   case CDV:                                                         \
     rc = geom_grad ? launch_bwd<TS, PPL, CDV, true>(BWD_ARGS)       \
@@ -380,19 +398,30 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
                              const int32_t *flatten_ids, int64_t n_isects, const float *render_alphas,
                              const int32_t *last_ids, const float *render_colors, int ed_channel,
                              const float *v_render_colors, const float *v_render_alphas, int absgrad, int geom_grad,
-                             float *v_geom, float *v_colors, void *stream) {
+                             float *v_geom, float *v_colors, const pr_color_segment *segments,
+                             const pr_grad_segment *v_segments, int n_segments, void *stream) {
   if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)
     return PR_EINVAL;
   if (tile_size != 16 && tile_size != 8) return PR_EUNSUPPORTED;
   if (D > pr_max_channels() || n_isects > 2147483647ll) return PR_EUNSUPPORTED;
   if ((int64_t)tile_w * tile_size < width || (int64_t)tile_h * tile_size < height) return PR_EINVAL;
   if (C == 0 || n_isects == 0) return PR_OK;
-  if (!means2d || !conics || !colors || !opacities || !isect_offsets || !flatten_ids || !render_alphas || !last_ids ||
+  if (!means2d || !conics || !opacities || !isect_offsets || !flatten_ids || !render_alphas || !last_ids ||
       !v_render_colors || !v_render_alphas)
     return PR_EINVAL;
+  if (n_segments > 0 && !v_segments) return PR_EINVAL;
+  ColorSegs cs;
+  GradSegs gs;
+  int rcs = make_color_segs(colors, D, segments, n_segments, true, cs);
+  if (!rcs) rcs = make_grad_segs(v_colors, D, v_segments, n_segments, gs);
+  if (rcs) return rcs;
+  for (int i = 0; i < gs.n; ++i)
+    if (n_segments > 0 && (gs.begin[i] != cs.begin[i])) return PR_EINVAL;  // widths must match the colours'
+  bool any_color_grad = false;
+  for (int i = 0; i < gs.n; ++i) any_color_grad = any_color_grad || gs.ptr[i] != nullptr;
   if (geom_grad && !v_geom) return PR_EINVAL;
   if (ed_channel >= D || (ed_channel >= 0 && !render_colors)) return PR_EINVAL;
-  if (!geom_grad && !v_colors) return PR_OK;
+  if (!geom_grad && !any_color_grad) return PR_OK;
   if ((int64_t)C * tile_w * tile_h * 4 > 2147483647ll) return PR_EUNSUPPORTED;
   const BwdPlan plan = plan_bwd(D, geom_grad, tile_size, (int64_t)C * tile_w * tile_h);
   for (int off = 0; off < D; off += plan.per) {

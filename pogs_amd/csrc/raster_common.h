@@ -79,13 +79,70 @@ struct alignas(16) WaveLds {
   float red[(round4(CD) / 4 + 2) * 68];
 };
 
+// The D composited channels of a Gaussian may live in up to three tensors laid side by side in channel order
+// (e.g. [rgb from SH | per-Gaussian features | depth]): segment i supplies channels [begin[i], begin[i+1]) from
+// rows of pitch ld[i]; a shared segment is indexed by n alone (one row per Gaussian for all cameras), the
+// others by the flat index c*N + n.  Unused trailing segments have begin = INT_MAX.  The compositor gathers
+// from (and the backward scatters into) the tensors where they are, so no [C,N,D] copy is ever assembled.
+struct ColorSegs {
+  const float *ptr[3];
+  int begin[3], ld[3], shared[3], n;
+};
+struct GradSegs {  // same layout for the colour gradients; ptr NULL = this segment needs no gradient
+  float *ptr[3];
+  int begin[3], ld[3], shared[3], n;
+};
+
+// Host side: the kernels' segment tables from the C-ABI arguments.  Without segments the single [C,N,D]
+// tensor is segment 0.  Widths must be positive and add up to D.
+template <class Segs, class Ptr, class AbiSeg>
+inline int make_segs(Ptr whole, int D, const AbiSeg *segments, int n_segments, bool need_ptrs, bool null_ok,
+                     Segs &out) {
+  for (int i = 0; i < 3; ++i) {
+    out.ptr[i] = nullptr;
+    out.begin[i] = 0x7fffffff;
+    out.ld[i] = 0;
+    out.shared[i] = 0;
+  }
+  if (n_segments < 0 || n_segments > 3) return PR_EINVAL;
+  if (n_segments == 0) {
+    if (need_ptrs && !whole && !null_ok) return PR_EINVAL;
+    out.ptr[0] = whole;
+    out.begin[0] = 0;
+    out.ld[0] = D;
+    out.n = 1;
+    return PR_OK;
+  }
+  if (!segments) return PR_EINVAL;
+  int at = 0;
+  for (int i = 0; i < n_segments; ++i) {
+    if (segments[i].width <= 0 || segments[i].ld < segments[i].width) return PR_EINVAL;
+    if (need_ptrs && !segments[i].ptr && !null_ok) return PR_EINVAL;
+    out.ptr[i] = segments[i].ptr;
+    out.begin[i] = at;
+    out.ld[i] = segments[i].ld;
+    out.shared[i] = segments[i].shared != 0;
+    at += segments[i].width;
+  }
+  if (at != D) return PR_EINVAL;
+  out.n = n_segments;
+  return PR_OK;
+}
+inline int make_color_segs(const float *colors, int D, const pr_color_segment *segments, int n_segments,
+                           bool need_ptrs, ColorSegs &out) {
+  return make_segs(colors, D, segments, n_segments, need_ptrs, false, out);
+}
+inline int make_grad_segs(float *v_colors, int D, const pr_grad_segment *segments, int n_segments, GradSegs &out) {
+  return make_segs(v_colors, D, segments, n_segments, true, true, out);
+}
+
 // Stage up to 64 intersections [first, first+count) of the sorted list: lane j loads Gaussian j.
 // Returns the wave-wide mask of staged Gaussians whose footprint reaches the region.
 template <int CD>
 __device__ __forceinline__ unsigned long long stage_batch(
     WaveLds<CD> &L, int lane, int first, int count, const int32_t *__restrict__ flatten_ids,
     const float *__restrict__ means2d, const float *__restrict__ conics, const float *__restrict__ opacities,
-    const float *__restrict__ colors, int D, int ch_off, float rx0, float ry0, float rx1, float ry1) {
+    const ColorSegs &cs, int N, int D, int ch_off, float rx0, float ry0, float rx1, float ry1) {
   constexpr int ROW = color_row(CD);
   bool keep = false;
   if (lane < count) {
@@ -98,10 +155,27 @@ __device__ __forceinline__ unsigned long long stage_batch(
       L.g4[lane] = make_float4(xy.x, xy.y, o, -0.5f * LOG2E * ca);
       L.g2[lane] = make_float2(-LOG2E * cb, -0.5f * LOG2E * cc);
       L.ids[lane] = g;
-      const float *src = colors + (int64_t)g * D + ch_off;
       int nch = D - ch_off;  // channels available from ch_off on
       float *dst = L.col + lane * ROW;
-      if (((D | ch_off) & 3) == 0) {
+      const float *src = cs.ptr[0] + (int64_t)g * cs.ld[0] + ch_off;
+      if (cs.n > 1 || cs.shared[0]) {
+        // channels gathered from several tensors: one pointer per segment, pre-offset so that [channel] indexes it
+        const int gn = g % N;
+        const float *b0 = cs.ptr[0] + (int64_t)(cs.shared[0] ? gn : g) * cs.ld[0] - cs.begin[0];
+        const float *b1 = cs.n > 1 ? cs.ptr[1] + (int64_t)(cs.shared[1] ? gn : g) * cs.ld[1] - cs.begin[1] : b0;
+        const float *b2 = cs.n > 2 ? cs.ptr[2] + (int64_t)(cs.shared[2] ? gn : g) * cs.ld[2] - cs.begin[2] : b0;
+#pragma unroll
+        for (int k = 0; k < round4(CD); k += 4) {
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int ch = ch_off + k + i;
+            const float *b = ch >= cs.begin[2] ? b2 : ch >= cs.begin[1] ? b1 : b0;
+            v[i] = (k + i < nch) ? b[ch] : 0.f;
+          }
+          *reinterpret_cast<float4 *>(dst + k) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      } else if (((cs.ld[0] | ch_off) & 3) == 0) {
 #pragma unroll
         for (int k = 0; k < round4(CD); k += 4) {
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);

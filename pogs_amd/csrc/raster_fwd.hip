@@ -8,7 +8,7 @@ namespace pr {
 template <int TS, int PPL, int CD>
 __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
+    const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
     const int32_t *__restrict__ tile_order, const int32_t *__restrict__ flatten_ids, int n_isects, int ed_channel, float *__restrict__ render_colors,
     float *__restrict__ render_alphas, int32_t *__restrict__ last_ids) {
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
   for (int first = range_lo; first < range_hi && !all_done; first += WAVE) {
     const int count = min(WAVE, range_hi - first);
     unsigned long long todo = stage_batch<CD>(L, lane, first, count, flatten_ids, means2d, conics, opacities,
-                                              colors, D, ch_off, rx0, ry0, rx1, ry1);
+                                              cs, N, D, ch_off, rx0, ry0, rx1, ry1);
     while (todo) {
       const int t = __builtin_ctzll(todo);
       todo &= todo - 1;
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
 }
 
 template <int TS, int PPL, int CD>
-static int launch_fwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const float *colors,
+static int launch_fwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const ColorSegs &cs,
                       const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
                       const int32_t *isect_offsets, const int32_t *tile_order, const int32_t *flatten_ids,
                       int64_t n_isects, int ed_channel,
@@ -164,7 +164,7 @@ static int launch_fwd(int C, int N, int D, int ch_off, const float *means2d, con
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
   const unsigned grid = (unsigned)((n_regions + WPB - 1) / WPB);
   hipLaunchKernelGGL((raster_fwd_kernel<TS, PPL, CD>), dim3(grid), dim3(64 * WPB), 0, stream, (int)n_regions, N, D, ch_off,
-                     means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
+                     means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
                      tile_order, flatten_ids, (int)n_isects, ed_channel, render_colors, render_alphas, last_ids);
   return check_launch("raster_fwd_kernel");
 }
@@ -217,7 +217,7 @@ static FwdPlan plan_fwd(int D, int tile_size, int64_t n_tiles_total) {
 using namespace pr;
 
 #define FWD_ARGS                                                                                                    \
-  C, N, D, off, means2d, conics, colors, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,      \
+  C, N, D, off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,          \
       tile_order, flatten_ids, n_isects, ed_channel, render_colors, render_alphas, last_ids, (hipStream_t)stream
 #define FWD_CASE(TS, PPL, CDV) \
   case CDV:                    \
@@ -228,7 +228,8 @@ extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const fl
                              const float *opacities, const float *backgrounds, int width, int height, int tile_size,
                              int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
                              const int32_t *flatten_ids, int64_t n_isects, int ed_channel, float *render_colors,
-                             float *render_alphas, int32_t *last_ids, void *stream) {
+                             float *render_alphas, int32_t *last_ids, const pr_color_segment *segments,
+                             int n_segments, void *stream) {
   if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)
     return PR_EINVAL;
   if (tile_size != 16 && tile_size != 8) return PR_EUNSUPPORTED;
@@ -237,8 +238,11 @@ extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const fl
   if (ed_channel >= D) return PR_EINVAL;
   if (C == 0) return PR_OK;
   if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return PR_EINVAL;
-  if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return PR_EINVAL;
+  if (n_isects > 0 && (!means2d || !conics || !opacities || !flatten_ids)) return PR_EINVAL;
   if ((int64_t)C * tile_w * tile_h * 4 > 2147483647ll) return PR_EUNSUPPORTED;
+  ColorSegs cs;
+  int rcs = make_color_segs(colors, D, segments, n_segments, n_isects > 0, cs);
+  if (rcs) return rcs;
   const FwdPlan plan = plan_fwd(D, tile_size, (int64_t)C * tile_w * tile_h);
   for (int off = 0; off < D; off += plan.per) {
     const int cd = pick_chunk(min(plan.per, D - off));

@@ -374,17 +374,33 @@ def _tile_order(isect_offsets: Tensor, n_isects: int) -> Optional[Tensor]:
     return torch.argsort(ends - o, descending=True).to(torch.int32)
 
 
+def _segments(parts, C, N):
+    """parts: tensors [C,N,w] (per camera) or [N,w] (shared by all cameras), in channel order ->
+    (contiguous tensors, [(ptr, width, ld, shared)])."""
+    tensors, items = [], []
+    for t in parts:
+        shared = t.dim() == 2
+        assert t.shape[:-1] == ((N,) if shared else (C, N)), t.shape
+        t = t.contiguous()
+        tensors.append(t)
+        items.append((t.data_ptr(), t.shape[-1], t.shape[-1], shared))
+    return tensors, items
+
+
 class _Rasterize(torch.autograd.Function):
-    """Tile compositing; stands in for gsplat ``rasterize_to_pixels``."""
+    """Tile compositing; stands in for gsplat ``rasterize_to_pixels``.  The composited channels are the
+    concatenation of up to three tensors (``part0 | part1 | part2``, each [C,N,w] or -- shared by all cameras --
+    [N,w]); the kernels gather from them in place and scatter the gradients into one buffer per part."""
 
     @staticmethod
-    def forward(ctx, means2d, conics, colors, opacities, backgrounds, width, height, tile_size, isect_offsets,
-                flatten_ids, absgrad, ed_channel, tile_order):
+    def forward(ctx, means2d, conics, part0, part1, part2, opacities, backgrounds, width, height, tile_size,
+                isect_offsets, flatten_ids, absgrad, ed_channel, tile_order):
         lib = _lib.load()
-        C, N, D = colors.shape
+        C, N = opacities.shape
         dev = means2d.device
-        means2d_c, conics, colors, opacities = (means2d.contiguous(), conics.contiguous(), colors.contiguous(),
-                                                opacities.contiguous())
+        parts, items = _segments([p for p in (part0, part1, part2) if p is not None], C, N)
+        D = sum(w for _, w, _, _ in items)
+        means2d_c, conics, opacities = means2d.contiguous(), conics.contiguous(), opacities.contiguous()
         backgrounds = None if backgrounds is None else backgrounds.contiguous()
         th, tw = isect_offsets.shape[1:]
         render_colors = torch.empty(C, height, width, D, dtype=torch.float32, device=dev)
@@ -392,24 +408,30 @@ class _Rasterize(torch.autograd.Function):
         last_ids = torch.empty(C, height, width, dtype=torch.int32, device=dev)
         if tile_order is None:
             tile_order = _tile_order(isect_offsets, flatten_ids.numel())
+        single = len(parts) == 1 and not items[0][3]
+        keep, segs = (None, None) if single else _lib.segment_array(items)
         with torch.cuda.device(dev):
-            _call("pr_raster_fwd", C, N, D, _ptr(means2d_c), _ptr(conics), _ptr(colors), _ptr(opacities),
-                                         _ptr(backgrounds), width, height, tile_size, tw, th, _ptr(isect_offsets),
-                                         _ptr(tile_order), _ptr(flatten_ids), flatten_ids.numel(), ed_channel, _ptr(render_colors),
-                                         _ptr(render_alphas), _ptr(last_ids), _stream())
-        ctx.save_for_backward(means2d_c, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids,
-                              render_alphas, last_ids, render_colors if ed_channel >= 0 else None, tile_order)
-        ctx.args = (width, height, tile_size, absgrad, ed_channel)
+            _call("pr_raster_fwd", C, N, D, _ptr(means2d_c), _ptr(conics), _ptr(parts[0]) if single else None,
+                  _ptr(opacities), _ptr(backgrounds), width, height, tile_size, tw, th, _ptr(isect_offsets),
+                  _ptr(tile_order), _ptr(flatten_ids), flatten_ids.numel(), ed_channel, _ptr(render_colors),
+                  _ptr(render_alphas), _ptr(last_ids), segs, 0 if single else len(items), _stream())
+        del keep
+        ctx.save_for_backward(means2d_c, conics, opacities, backgrounds, isect_offsets, flatten_ids,
+                              render_alphas, last_ids, render_colors if ed_channel >= 0 else None, tile_order,
+                              *parts)
+        ctx.args = (width, height, tile_size, absgrad, ed_channel, items,
+                    [i for i, p in enumerate((part0, part1, part2)) if p is not None])
         ctx.means2d_obj = means2d  # the object callers hold in meta["means2d"]; receives .absgrad
         return render_colors, render_alphas
 
     @staticmethod
     def backward(ctx, v_render_colors, v_render_alphas):
         lib = _lib.load()
-        (means2d, conics, colors, opacities, backgrounds, isect_offsets, flatten_ids, render_alphas,
-         last_ids, render_colors, tile_order) = ctx.saved_tensors
-        width, height, tile_size, absgrad, ed_channel = ctx.args
-        C, N, D = colors.shape
+        (means2d, conics, opacities, backgrounds, isect_offsets, flatten_ids, render_alphas, last_ids,
+         render_colors, tile_order, *parts) = ctx.saved_tensors
+        width, height, tile_size, absgrad, ed_channel, items, slots = ctx.args
+        C, N = opacities.shape
+        D = sum(w for _, w, _, _ in items)
         dev = means2d.device
         th, tw = isect_offsets.shape[1:]
         if v_render_colors is None:
@@ -417,18 +439,22 @@ class _Rasterize(torch.autograd.Function):
         if v_render_alphas is None:
             v_render_alphas = torch.zeros(C, height, width, 1, dtype=torch.float32, device=dev)
         v_render_colors, v_render_alphas = v_render_colors.contiguous(), v_render_alphas.contiguous()
-        geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
-        want_colors = ctx.needs_input_grad[2]
+        geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[5]
         v_geom = torch.zeros(C * N, 8, dtype=torch.float32, device=dev) if geom else None
-        v_colors = torch.zeros(C, N, D, dtype=torch.float32, device=dev) if want_colors else None
-        if geom or want_colors:
+        v_parts = [torch.zeros_like(p) if ctx.needs_input_grad[2 + slot] else None for p, slot in zip(parts, slots)]
+        if geom or any(v is not None for v in v_parts):
+            single = len(parts) == 1 and not items[0][3]
+            keep_c, segs = (None, None) if single else _lib.segment_array(items)
+            keep_g, vsegs = (None, None) if single else _lib.segment_array(
+                [(None if v is None else v.data_ptr(), w, ld, sh) for v, (_, w, ld, sh) in zip(v_parts, items)])
             with torch.cuda.device(dev):
-                _call("pr_raster_bwd", C, N, D, _ptr(means2d), _ptr(conics), _ptr(colors), _ptr(opacities),
-                                             _ptr(backgrounds), width, height, tile_size, tw, th,
-                                             _ptr(isect_offsets), _ptr(tile_order), _ptr(flatten_ids),
-                                             flatten_ids.numel(), _ptr(render_alphas), _ptr(last_ids), _ptr(render_colors), ed_channel,
-                                             _ptr(v_render_colors), _ptr(v_render_alphas), int(absgrad),
-                                             int(geom), _ptr(v_geom), _ptr(v_colors), _stream())
+                _call("pr_raster_bwd", C, N, D, _ptr(means2d), _ptr(conics), _ptr(parts[0]) if single else None,
+                      _ptr(opacities), _ptr(backgrounds), width, height, tile_size, tw, th, _ptr(isect_offsets),
+                      _ptr(tile_order), _ptr(flatten_ids), flatten_ids.numel(), _ptr(render_alphas), _ptr(last_ids),
+                      _ptr(render_colors), ed_channel, _ptr(v_render_colors), _ptr(v_render_alphas), int(absgrad),
+                      int(geom), _ptr(v_geom), _ptr(v_parts[0]) if single else None, segs, vsegs,
+                      0 if single else len(items), _stream())
+            del keep_c, keep_g
         v_means2d = v_conics = v_opacities = None
         if geom:
             g = v_geom.view(C, N, 8)
@@ -436,99 +462,35 @@ class _Rasterize(torch.autograd.Function):
             if absgrad:
                 ctx.means2d_obj.absgrad = g[..., 6:8]
         v_backgrounds = None
-        if backgrounds is not None and ctx.needs_input_grad[4]:
+        if backgrounds is not None and ctx.needs_input_grad[6]:
             v_backgrounds = (v_render_colors * (1.0 - render_alphas)).sum(dim=(1, 2))
             if ed_channel >= 0:
                 v_backgrounds[:, ed_channel] = (v_render_colors[..., ed_channel] * (1.0 - render_alphas[..., 0])
                                                 / render_alphas[..., 0].clamp(min=1e-10)).sum(dim=(1, 2))
         ctx.means2d_obj = None
+        v_slots = [None, None, None]
+        for v, slot in zip(v_parts, slots):
+            v_slots[slot] = v
         return (v_means2d if ctx.needs_input_grad[0] else None, v_conics if ctx.needs_input_grad[1] else None,
-                v_colors, v_opacities if ctx.needs_input_grad[3] else None, v_backgrounds, None, None, None, None,
-                None, None, None, None)
+                v_slots[0], v_slots[1], v_slots[2], v_opacities if ctx.needs_input_grad[5] else None, v_backgrounds,
+                None, None, None, None, None, None, None, None)
 
 
 def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor, image_width: int,
                         image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
                         backgrounds: Optional[Tensor] = None, absgrad: bool = False,
-                        ed_channel: int = -1, tile_order: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+                        ed_channel: int = -1, tile_order: Optional[Tensor] = None,
+                        more_colors: Tuple[Tensor, ...] = ()) -> Tuple[Tensor, Tensor]:
     """Stands in for gsplat ``rasterize_to_pixels`` (non-packed): [C,N,*] inputs ->
-    render_colors [C,H,W,D], render_alphas [C,H,W,1].  ``ed_channel`` (extension): index of a depth
-    channel to output as expected depth, accumulated depth / max(alpha, 1e-10); -1 = none.  ``tile_order``
-    (extension): launch order of the tiles as ``_bin_tiles`` returns it; derived here when not given."""
-    return _Rasterize.apply(means2d, conics, colors, opacities, backgrounds, image_width, image_height, tile_size,
-                            isect_offsets, flatten_ids, absgrad, int(ed_channel), tile_order)
-
-
-class _AssembleColors(torch.autograd.Function):
-    """Builds the per-Gaussian channel buffer the compositor reads, [C,N,D] = [rgb | features | depth], in
-    place: SH colours are evaluated straight into columns 0..2 (or given colours copied there), features and
-    depths are strided copies.  Backward hands out column views of the incoming gradient -- no concatenation
-    or split copies either way."""
-
-    @staticmethod
-    def forward(ctx, sh_degree, means, campos, colors, radii, features, depths, C):
-        N = means.shape[0]
-        dev = means.device
-        n_col = 0 if colors is None else (3 if sh_degree is not None else colors.shape[-1])
-        n_feat = 0 if features is None else features.shape[-1]
-        n_dep = 0 if depths is None else 1
-        D = n_col + n_feat + n_dep
-        out = torch.empty(C, N, D, dtype=torch.float32, device=dev)
-        coeffs = None
-        if colors is not None:
-            if sh_degree is not None:
-                coeffs = colors.contiguous()
-                means_c, campos_c = means.contiguous(), campos.contiguous()
-                with torch.cuda.device(dev):
-                    _call("pr_sh_fwd", C, N, coeffs.shape[1], sh_degree, _ptr(means_c), _ptr(campos_c), _ptr(coeffs),
-                          _ptr(radii), 1, _ptr(out), D, _stream())
-                ctx.save_for_backward(means_c, campos_c, coeffs, radii)
-            else:
-                out[..., :n_col].copy_(colors if colors.dim() == 3 else colors[None].expand(C, -1, -1))
-        if features is not None:
-            out[..., n_col:n_col + n_feat].copy_(features[None].expand(C, -1, -1))
-        if depths is not None:
-            out[..., D - 1].copy_(depths)
-        ctx.layout = (sh_degree, n_col, n_feat, n_dep, C, N, None if colors is None else colors.dim())
-        return out
-
-    @staticmethod
-    def backward(ctx, v_out):
-        sh_degree, n_col, n_feat, n_dep, C, N, colors_dim = ctx.layout
-        D = n_col + n_feat + n_dep
-        dev = v_out.device
-        v_means = v_campos = v_colors = v_features = v_depths = None
-        if n_col and ctx.needs_input_grad[3]:
-            if sh_degree is not None:
-                means, campos, coeffs, radii = ctx.saved_tensors
-                K = coeffs.shape[1]
-                v, ld = _rows(v_out, D)
-                v_colors = torch.empty(N, K, 3, dtype=torch.float32, device=dev)
-                v_means = torch.empty(N, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
-                v_campos = torch.zeros(C, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
-                with torch.cuda.device(dev):
-                    _call("pr_sh_bwd", C, N, K, sh_degree, _ptr(means), _ptr(campos), _ptr(coeffs), _ptr(radii), 1,
-                          _ptr(v), ld, _ptr(v_colors), _ptr(v_means), _ptr(v_campos), _stream())
-            else:
-                v_colors = v_out[..., :n_col]
-                if colors_dim == 2:
-                    v_colors = v_colors[0] if C == 1 else v_colors.sum(0)
-        elif n_col and sh_degree is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
-            means, campos, coeffs, radii = ctx.saved_tensors
-            K = coeffs.shape[1]
-            v, ld = _rows(v_out, D)
-            scratch = torch.empty(N, K, 3, dtype=torch.float32, device=dev)
-            v_means = torch.empty(N, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
-            v_campos = torch.zeros(C, 3, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
-            with torch.cuda.device(dev):
-                _call("pr_sh_bwd", C, N, K, sh_degree, _ptr(means), _ptr(campos), _ptr(coeffs), _ptr(radii), 1,
-                      _ptr(v), ld, _ptr(scratch), _ptr(v_means), _ptr(v_campos), _stream())
-        if n_feat and ctx.needs_input_grad[5]:
-            v_features = v_out[..., n_col:n_col + n_feat]
-            v_features = v_features[0] if C == 1 else v_features.sum(0)
-        if n_dep and ctx.needs_input_grad[6]:
-            v_depths = v_out[..., D - 1]
-        return None, v_means, v_campos, v_colors, None, v_features, v_depths, None
+    render_colors [C,H,W,D], render_alphas [C,H,W,1].  Extensions: ``ed_channel``, index of a depth
+    channel to output as expected depth, accumulated depth / max(alpha, 1e-10), -1 = none; ``tile_order``,
+    launch order of the tiles as ``_bin_tiles`` returns it, derived here when not given; ``more_colors``, up to
+    two further tensors ([C,N,w], or [N,w] shared by all cameras) whose channels follow those of ``colors``
+    -- composited in the same pass without being concatenated."""
+    parts = (colors,) + tuple(more_colors) + (None, None)
+    assert len(more_colors) <= 2
+    return _Rasterize.apply(means2d, conics, parts[0], parts[1], parts[2], opacities, backgrounds, image_width,
+                            image_height, tile_size, isect_offsets, flatten_ids, absgrad, int(ed_channel), tile_order)
 
 
 def fully_fused_projection(means, quats, scales, viewmats, Ks, width, height, eps2d=0.3, near_plane=0.01,
@@ -630,17 +592,25 @@ def rasterization(
                 raise NotImplementedError("per-camera SH coefficients with C > 1")
             colors = colors[0]
         campos = camera_centers(viewmats)
-    # one buffer [C,N,D] = [rgb or given colours | features | depth], written in place (no concatenations)
-    cols = _AssembleColors.apply(
-        None if sh_degree is None else int(sh_degree), means, campos, None if depth_only else colors, radii,
-        None if depth_only else features, depths if with_depth else None, C)
+    # channels = [rgb or given colours | features | depth]: the compositor gathers from the tensors in place
+    parts = []
+    if not depth_only:
+        if sh_degree is not None:
+            parts.append(_SphericalHarmonics.apply(int(sh_degree), means, campos, colors, radii, True))
+        else:
+            parts.append(colors)            # [C,N,D], or [N,D] shared by all cameras
+        if features is not None:
+            parts.append(features)          # [N,F], shared
+    if with_depth:
+        parts.append(depths[..., None])     # [C,N,1]
+    n_channels = sum(p.shape[-1] for p in parts)
     bgs = backgrounds
     if bgs is not None:
         if depth_only:
             bgs = torch.zeros(C, 1, device=bgs.device, dtype=bgs.dtype)
         elif with_depth:
             bgs = torch.cat([bgs, torch.zeros(C, 1, device=bgs.device, dtype=bgs.dtype)], dim=-1)
-        assert bgs.shape == (C, cols.shape[-1]), bgs.shape
+        assert bgs.shape == (C, n_channels), bgs.shape
 
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
@@ -651,10 +621,10 @@ def rasterization(
         opacities=opac)
 
     # expected depth (ED): the depth channel is divided by max(alpha, 1e-10) inside the kernels
-    ed_channel = cols.shape[-1] - 1 if render_mode in ("ED", "RGB+ED") else -1
+    ed_channel = n_channels - 1 if render_mode in ("ED", "RGB+ED") else -1
     render_colors, render_alphas = rasterize_to_pixels(
-        means2d, conics, cols, opac, width, height, tile_size, isect_offsets, flatten_ids, backgrounds=bgs,
-        absgrad=absgrad, ed_channel=ed_channel, tile_order=tile_order)
+        means2d, conics, parts[0], opac, width, height, tile_size, isect_offsets, flatten_ids, backgrounds=bgs,
+        absgrad=absgrad, ed_channel=ed_channel, tile_order=tile_order, more_colors=tuple(parts[1:]))
 
     meta = RenderMeta({
         "camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths,

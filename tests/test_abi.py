@@ -53,14 +53,23 @@ def test_argument_validation_needs_no_gpu():
     assert lib.pr_project_fwd(1, 4, None, None, None, None, None, 8, 8, 0.3, 0.01, 1e10, 0.0,
                               None, None, None, None, None, None) == -1          # null pointers
     assert lib.pr_sh_fwd(1, 4, 16, 4, None, None, None, None, 1, None, 3, None) == -2   # degree 4 unsupported
+    tail = (None, None, None, None, 0, None)  # render_colors, render_alphas, last_ids, segments, n_segments, stream
     assert lib.pr_raster_fwd(1, 4, 3, None, None, None, None, None, 64, 64, 12, 6, 6, None, None, None, 0, -1,
-                             None, None, None, None) == -2                        # tile size 12 unsupported
+                             *tail) == -2                        # tile size 12 unsupported
     assert lib.pr_raster_fwd(1, 4, 3, None, None, None, None, None, 64, 64, 16, 2, 2, None, None, None, 0, -1,
-                             None, None, None, None) == -1                        # tile grid does not cover the image
+                             *tail) == -1                        # tile grid does not cover the image
     assert lib.pr_raster_fwd(1, 4, 3, None, None, None, None, None, 64, 64, 16, 4, 4, None, None, None, 0, 3,
-                             None, None, None, None) == -1                        # depth channel index out of range
+                             *tail) == -1                        # depth channel index out of range
     assert lib.pr_raster_fwd(1, 4, 101, None, None, None, None, None, 64, 64, 16, 4, 4, None, None, None, 0, -1,
-                             None, None, None, None) == -2                        # more channels than any kernel takes
+                             *tail) == -2                        # more channels than any kernel takes
+    # channel segments: widths must add up to D, at most three
+    keep, segs = _lib.segment_array([(None, 3, 3, 0), (None, 2, 2, 1)])
+    out = ctypes.create_string_buffer(64)   # stands in for the output pointers: rejected before any use
+    o = ctypes.cast(out, ctypes.c_void_p)
+    assert lib.pr_raster_fwd(1, 4, 6, None, None, None, None, None, 64, 64, 16, 4, 4, o, None, None, 0, -1,
+                             o, o, o, segs, 2, None) == -1       # 3 + 2 != 6
+    assert lib.pr_raster_fwd(1, 4, 5, None, None, None, None, None, 64, 64, 16, 4, 4, o, None, None, 0, -1,
+                             o, o, o, segs, 4, None) == -1       # more than three segments
 
 
 def test_rasterization_fails_loudly_without_gpu_tensors():

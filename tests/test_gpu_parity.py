@@ -337,6 +337,44 @@ def test_raster_backward(gpu, tile_size, D, with_bg):
     assert (ab + 1e-6 * ab.abs().max() >= leaves["means2d"].grad.abs()).all()
 
 
+@pytest.mark.parametrize("tile_size,widths", [(16, (3, 32, 1)), (8, (5, 7)), (16, (40, 30, 1))])
+def test_channels_gathered_from_several_tensors_match_one_concatenated_tensor(gpu, tile_size, widths):
+    """[C,N,w0] | [N,w1] shared by both cameras | [C,N,w2] composited in place == their concatenation."""
+    rd = _rendering()
+    C = 2
+    sc = small_scene(n=400, w=80, h=48, views=C, seed=6, lo=0.02, hi=0.3)
+    a = scene_args(sc, device=gpu)
+    radii, means2d, depths, conics, _ = rd.fully_fused_projection(
+        a["means"], a["quats"], a["scales"], a["viewmats"], a["Ks"], sc.width, sc.height)
+    opac = a["opacities"][None].expand(C, -1).contiguous()
+    tw, th = math.ceil(sc.width / tile_size), math.ceil(sc.height / tile_size)
+    _, _, flat, offs = rd._bin_tiles(means2d, radii, depths, tile_size, tw, th, False, True)
+    g = torch.Generator().manual_seed(3)
+    N = sc.means.shape[0]
+    parts = []
+    for i, w in enumerate(widths):
+        shape = (N, w) if i == 1 else (C, N, w)
+        parts.append(torch.rand(shape, generator=g).to(gpu).requires_grad_(True))
+    cat = torch.cat([p if p.dim() == 3 else p[None].expand(C, -1, -1) for p in parts], dim=-1)
+    cat = cat.detach().requires_grad_(True)
+    D = sum(widths)
+    vc = torch.randn(C, sc.height, sc.width, D, generator=g).to(gpu)
+    m1, m2 = means2d.detach().requires_grad_(True), means2d.detach().requires_grad_(True)
+    out1, al1 = rd.rasterize_to_pixels(m1, conics, cat, opac, sc.width, sc.height, tile_size, offs, flat)
+    out2, al2 = rd.rasterize_to_pixels(m2, conics, parts[0], opac, sc.width, sc.height, tile_size, offs, flat,
+                                       more_colors=tuple(parts[1:]))
+    assert torch.equal(out1, out2) and torch.equal(al1, al2)
+    (out1 * vc).sum().backward()
+    (out2 * vc).sum().backward()
+    at = 0
+    for i, (p, w) in enumerate(zip(parts, widths)):
+        ref = cat.grad[..., at:at + w]
+        ref = ref.sum(0) if p.dim() == 2 else ref
+        assert_grad_close(p.grad, ref, f"part {i}", rtol=1e-4)
+        at += w
+    assert_grad_close(m2.grad, m1.grad, "means2d", rtol=1e-4)
+
+
 def test_raster_backward_colors_only(gpu):
     """Geometry detached (the training-time feature pass, pogs/pogs.py:494-498): only colour gradients."""
     rd = _rendering()
