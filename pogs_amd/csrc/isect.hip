@@ -71,97 +71,163 @@ __device__ __noinline__ bool touches_tile(float gx, float gy, float o, float a, 
   return touches_region(gx, gy, o, a, b, c, rx0, ry0, rx1, ry1);
 }
 
-struct WaveCandidates {  // per lane: one Gaussian and its bounding-box tiles
-  float gx, gy, o, a, b, c;
-  int x0, y0, w, cnt, cstart, total;
+// Candidate tiles of one Gaussian: gsplat's bounding-box rectangle, clipped to the axis-aligned box of the
+// alpha = 1/255 level set (half extents sqrt(2 t c / det), sqrt(2 t a / det), t = ln(255 o), slightly
+// enlarged so that it never excludes a tile the exact test would keep).  Out of line for the same reason as
+// touches_tile: count and emission must see identical rectangles.
+struct Candidates {
+  int x0, y0, w, cnt;
+};
+__device__ __noinline__ Candidates candidate_rect(float gx, float gy, int rad, float o, float a, float b, float c,
+                                                  float ts, int tile_w, int tile_h) {
+  Candidates r = {0, 0, 1, 0};
+  TileRect t = tile_rect(gx, gy, rad, ts, tile_w, tile_h);
+  if (a > 0.f && c > 0.f && a * c - b * b > 0.f) {
+    const float lvl = __logf(255.f * o) + 4e-3f;
+    if (!(lvl > 0.f)) return r;  // cannot reach 1/255 anywhere
+    const float det = a * c - b * b;
+    const float ex = sqrtf(2.f * lvl * c / det) * 1.0001f + 1e-3f, ey = sqrtf(2.f * lvl * a / det) * 1.0001f + 1e-3f;
+    // tile x holds pixel centres [x ts + 0.5, x ts + ts - 0.5]
+    const float xl = ceilf((gx - ex + 0.5f) / ts - 1.f), xh = floorf((gx + ex - 0.5f) / ts);
+    const float yl = ceilf((gy - ey + 0.5f) / ts - 1.f), yh = floorf((gy + ey - 0.5f) / ts);
+    t.x0 = max(t.x0, (int)fmaxf(xl, 0.f));
+    t.y0 = max(t.y0, (int)fmaxf(yl, 0.f));
+    t.x1 = min(t.x1, (int)fminf(xh, (float)tile_w) + 1);
+    t.y1 = min(t.y1, (int)fminf(yh, (float)tile_h) + 1);
+  }
+  if (t.x1 > t.x0 && t.y1 > t.y0) {
+    r.x0 = t.x0;
+    r.y0 = t.y0;
+    r.w = t.x1 - t.x0;
+    r.cnt = r.w * (t.y1 - t.y0);
+  }
+  return r;
+}
+
+// Lanes of one wavefront exchange data through LDS without a workgroup barrier (LDS operations of a wave
+// complete in order); this only stops the COMPILER from keeping a lane's own store in a register or moving
+// accesses across the exchange point.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Per-wave LDS records for the cooperative enumeration: the 64 Gaussians of a wave, with candidates.
+struct alignas(16) WaveRecords {
+  float4 ga[WAVE];     // gx, gy, opacity, conic a
+  float4 gb[WAVE];     // conic b, conic c, 1/w, bit_cast(x0 | y0 << 16)
+  int2 gc[WAVE];       // first candidate number, w
+  uint2 gd[WAVE];      // camera bits of the key, flat Gaussian index
+  int owner[WAVE];     // scratch for the owner search of one chunk of 64 candidates
 };
 
-// Loads lane's Gaussian `idx` (or nothing when !valid) and scans the bounding-box tile counts over the wave.
-__device__ __forceinline__ WaveCandidates load_candidates(bool valid, int64_t idx, const float *__restrict__ means2d,
-                                                          const int32_t *__restrict__ radii,
-                                                          const float *__restrict__ conics,
-                                                          const float *__restrict__ opacities, float ts, int tile_w,
-                                                          int tile_h, int lane) {
-  WaveCandidates g = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0, 0, 1, 0, 0, 0};
+// Lane's Gaussian `idx` (nothing when !valid) -> its LDS record; returns the wave's candidate total.
+__device__ __forceinline__ int load_records(WaveRecords &R, bool valid, int64_t idx, uint32_t key_hi,
+                                            const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+                                            const float *__restrict__ conics, const float *__restrict__ opacities,
+                                            float ts, int tile_w, int tile_h, int lane, int &cnt, int &cstart) {
+  float gx = 0.f, gy = 0.f, o = 0.f, a = 0.f, b = 0.f, c = 0.f;
+  Candidates r = {0, 0, 1, 0};
   if (valid) {
     const int rad = radii[idx];
     if (rad > 0) {
-      g.gx = means2d[2 * idx];
-      g.gy = means2d[2 * idx + 1];
-      TileRect t = tile_rect(g.gx, g.gy, rad, ts, tile_w, tile_h);
-      const int n = (t.x1 - t.x0) * (t.y1 - t.y0);
-      if (n > 0) {
-        g.x0 = t.x0;
-        g.y0 = t.y0;
-        g.w = t.x1 - t.x0;
-        g.cnt = n;
-        g.a = conics[3 * idx];
-        g.b = conics[3 * idx + 1];
-        g.c = conics[3 * idx + 2];
-        g.o = opacities[idx];
-      }
+      gx = means2d[2 * idx];
+      gy = means2d[2 * idx + 1];
+      a = conics[3 * idx];
+      b = conics[3 * idx + 1];
+      c = conics[3 * idx + 2];
+      o = opacities[idx];
+      r = candidate_rect(gx, gy, rad, o, a, b, c, ts, tile_w, tile_h);
     }
   }
-  int incl = g.cnt;  // inclusive scan over the 64 lanes
+  cnt = r.cnt;
+  int incl = cnt;  // inclusive scan over the 64 lanes
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const int up = __shfl_up(incl, d);
     if (lane >= d) incl += up;
   }
-  g.cstart = incl - g.cnt;
-  g.total = __shfl(incl, 63);
-  return g;
+  cstart = incl - cnt;
+  R.ga[lane] = make_float4(gx, gy, o, a);
+  R.gb[lane] = make_float4(b, c, 1.f / (float)r.w, __int_as_float(r.x0 | (r.y0 << 16)));
+  R.gc[lane] = make_int2(cstart, r.w);
+  R.gd[lane] = make_uint2(key_hi, (uint32_t)idx);
+  wave_lds_sync();
+  return __shfl(incl, 63);
 }
 
-// Candidate number c of the wave -> which lane's Gaussian (j) and which tile; returns whether it passes.
-__device__ __forceinline__ bool test_candidate(const WaveCandidates &g, int c, float ts, int &j, int &tile_x,
-                                               int &tile_y) {
-  j = 0;  // last lane whose first candidate is <= c
-#pragma unroll
-  for (int step = 32; step >= 1; step >>= 1) {
-    const int sc = __shfl(g.cstart, (j + step) & 63);
-    if (j + step < 64 && sc <= c) j += step;
-  }
-  const int t = c - __shfl(g.cstart, j);
-  const int wj = __shfl(g.w, j);
-  const int ty = t / wj, tx = t - ty * wj;
-  tile_x = __shfl(g.x0, j) + tx;
-  tile_y = __shfl(g.y0, j) + ty;
-  const float gx = __shfl(g.gx, j), gy = __shfl(g.gy, j), o = __shfl(g.o, j);
-  const float a = __shfl(g.a, j), b = __shfl(g.b, j), cc = __shfl(g.c, j);
-  if (c >= g.total) return false;
+// One chunk of 64 candidates starting at c0: which Gaussian (record j) and which tile each lane's candidate
+// is, and whether it passes the footprint test.  `carry` is the owner of the candidate just before c0.
+// Owners are found by having every Gaussian whose first candidate lies in the chunk mark that position and
+// taking a running maximum over the lanes -- two LDS round trips instead of a six-step search.
+__device__ __forceinline__ bool test_chunk(WaveRecords &R, int c0, int total, int lane, int cnt, int cstart, float ts,
+                                           int &carry, int &j, int &tile_x, int &tile_y) {
+  R.owner[lane] = 0;
+  wave_lds_sync();
+  const int rel = cstart - c0;
+  if (cnt > 0 && rel >= 0 && rel < WAVE) R.owner[rel] = lane + 1;
+  wave_lds_sync();
+  int own = R.owner[lane];
+  wave_lds_sync();
+  // inclusive running maximum over lanes 0..lane (markers increase with the lane that wrote them)
+  own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x111, 0xf, 0xf, true));  // row_shr:1
+  own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x112, 0xf, 0xf, true));  // row_shr:2
+  own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x114, 0xf, 0xf, true));  // row_shr:4
+  own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x118, 0xf, 0xf, true));  // row_shr:8
+  own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x142, 0xa, 0xf, true));  // row_bcast:15 -> rows 1,3
+  own = max(own, __builtin_amdgcn_update_dpp(0, own, 0x143, 0xc, 0xf, true));  // row_bcast:31 -> rows 2,3
+  j = own > 0 ? own - 1 : carry;
+  carry = __builtin_amdgcn_readlane(j, 63);
+  const int c = c0 + lane;
+  const float4 ga = R.ga[j], gb = R.gb[j];
+  const int2 gc = R.gc[j];
+  const int t = c - gc.x;
+  const int ty = (int)(((float)t + 0.5f) * gb.z);  // t / w: (t + 0.5) / w is never within 0.004 of an integer
+  const int tx = t - ty * gc.y;
+  const int xy = __float_as_int(gb.w);
+  tile_x = (xy & 0xffff) + tx;
+  tile_y = (xy >> 16) + ty;
+  if (c >= total) return false;
   const float rx0 = (float)tile_x * ts + 0.5f, ry0 = (float)tile_y * ts + 0.5f;
-  return touches_tile(gx, gy, o, a, b, cc, rx0, ry0, rx0 + ts - 1.f, ry0 + ts - 1.f);
+  return touches_tile(ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, rx0, ry0, rx0 + ts - 1.f, ry0 + ts - 1.f);
 }
 
 __global__ void __launch_bounds__(256) isect_count_tight_kernel(
     int64_t total, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
     const float *__restrict__ conics, const float *__restrict__ opacities, float ts, int tile_w, int tile_h,
     int32_t *__restrict__ tiles_per_gauss) {
+  __shared__ WaveRecords recs[4];
   __shared__ int counts[256];
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
+  WaveRecords &R = recs[threadIdx.x >> 6];
   int *mine = counts + (threadIdx.x & ~63);
   mine[lane] = 0;
-  const WaveCandidates g = load_candidates(idx < total, idx, means2d, radii, conics, opacities, ts, tile_w, tile_h, lane);
-  for (int c0 = 0; c0 < g.total; c0 += 64) {
+  int cnt, cstart;
+  const int n_cand = load_records(R, idx < total, idx, 0u, means2d, radii, conics, opacities, ts, tile_w, tile_h, lane,
+                                  cnt, cstart);
+  int carry = 0;
+  for (int c0 = 0; c0 < n_cand; c0 += WAVE) {
     int j, tx, ty;
-    if (test_candidate(g, c0 + lane, ts, j, tx, ty)) atomicAdd(&mine[j], 1);
+    if (test_chunk(R, c0, n_cand, lane, cnt, cstart, ts, carry, j, tx, ty)) atomicAdd(&mine[j], 1);
   }
   if (idx < total) tiles_per_gauss[idx] = mine[lane];
 }
 
-// Footprint-tested emission: like isect_emit_sorted_kernel, but the wave enumerates the bounding-box tiles
-// of its 64 Gaussians as candidates and writes only those that pass, compacted in candidate order.
+// Footprint-tested emission: like isect_emit_sorted_kernel, but the wave enumerates the candidate tiles of its
+// 64 Gaussians and writes only those that pass, compacted in candidate order.
 __global__ void __launch_bounds__(256) isect_emit_tight_kernel(
     int64_t total, int N, const uint32_t *__restrict__ order, const uint32_t *__restrict__ starts,
     const float *__restrict__ means2d, const int32_t *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ opacities, const int32_t *__restrict__ tiles_per_gauss, float ts, int tile_w,
     int tile_h, int tile_bits, int64_t cap, const int64_t *__restrict__ n_dev, uint32_t *__restrict__ keys,
     uint32_t *__restrict__ vals) {
+  __shared__ WaveRecords recs[4];
   const int64_t n_isects = n_dev ? (*n_dev < cap ? *n_dev : cap) : cap;
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
+  WaveRecords &R = recs[threadIdx.x >> 6];
   uint32_t idx = 0, start = 0;
   bool valid = false;
   if (r < total) {
@@ -169,19 +235,21 @@ __global__ void __launch_bounds__(256) isect_emit_tight_kernel(
     start = starts[r];
     valid = tiles_per_gauss[idx] > 0;
   }
-  const WaveCandidates g = load_candidates(valid, (int64_t)idx, means2d, radii, conics, opacities, ts, tile_w, tile_h, lane);
-  const uint32_t hi = (idx / (uint32_t)N) << tile_bits;
-  int64_t pos = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)start, 0);  // lane 0 is always in range
-  for (int c0 = 0; c0 < g.total; c0 += 64) {
+  int cnt, cstart;
+  const int n_cand = load_records(R, valid, (int64_t)idx, (idx / (uint32_t)N) << tile_bits, means2d, radii, conics,
+                                  opacities, ts, tile_w, tile_h, lane, cnt, cstart);
+  int64_t pos = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)start, 0);
+  int carry = 0;
+  for (int c0 = 0; c0 < n_cand; c0 += WAVE) {
     int j, tx, ty;
-    const bool pass = test_candidate(g, c0 + lane, ts, j, tx, ty);
+    const bool pass = test_chunk(R, c0, n_cand, lane, cnt, cstart, ts, carry, j, tx, ty);
     const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-    const uint32_t hj = (uint32_t)__shfl((int)hi, j), ij = (uint32_t)__shfl((int)idx, j);
     if (pass) {
       const int64_t k = pos + __builtin_popcountll(m & ((1ull << lane) - 1ull));
       if (k < n_isects) {
-        keys[k] = hj | (uint32_t)(ty * tile_w + tx);
-        vals[k] = ij;
+        const uint2 gd = R.gd[j];
+        keys[k] = gd.x | (uint32_t)(ty * tile_w + tx);
+        vals[k] = gd.y;
       }
     }
     pos += __builtin_popcountll(m);
