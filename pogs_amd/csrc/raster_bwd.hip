@@ -17,6 +17,8 @@
 // four 16-byte loads, adds them, and issues the atomic -- contiguous addresses per Gaussian.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "raster_common.h"
 
 namespace pr {
@@ -38,8 +40,6 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
   constexpr int CDP = round4(CD);
   constexpr int NQ = CDP / 4;                 // colour quads
   constexpr int NV = CDP + (GEOM ? 8 : 0);    // values reduced per Gaussian
-  // colour quads handled per pass over the pixel slots (one wave-uniform branch per slot and pass)
-  constexpr int QG = NQ % 3 == 0 ? 3 : NQ % 4 == 0 ? 4 : NQ % 5 == 0 ? 5 : NQ % 2 == 0 ? 2 : 1;
   __shared__ WaveLds<CD> lds[WPB];
   const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // Without an explicit order, blocks that share an XCD take a contiguous range of tiles (neighbouring
@@ -206,61 +206,44 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
       }
 #endif
 
-      // With SLOT_SKIP the work of a pixel slot is skipped when no lane has an active pixel in it
-      // (wave-uniform branches; an inactive pixel contributes exact zeros to every sum).
-      float fac[PPL], ra[PPL];
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) {
-        ra[j] = 0.f;
-        fac[j] = 0.f;
-        if (!SLOT_SKIP || PPL == 1 || slot[j] != 0ull) {
-          ra[j] = __builtin_amdgcn_rcpf(1.f - alpha[j]);
-          T[j] = active[j] ? T[j] * ra[j] : T[j];
-          fac[j] = active[j] ? alpha[j] * T[j] : 0.f;
-        }
-      }
-      f2 S2[PPL];
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) S2[j] = splat(0.f);
       const float4 *crow = reinterpret_cast<const float4 *>(L.col + t * ROW);
       const int gid = L.ids[t];
       float *red = L.red;
+      // Pixel slots J0..J1-1 of every lane; slots outside the range are known to have no active pixel in
+      // any lane (an inactive pixel contributes exact zeros to every sum and leaves its state untouched).
+      auto composite = [&](auto j0c, auto j1c) {
+        constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+        float fac[PPL], ra[PPL];
+        f2 S2[PPL];
 #pragma unroll
-      for (int q0 = 0; q0 < NQ; q0 += QG) {
-        f2 c01[QG], c23[QG], a01[QG], a23[QG];
+        for (int j = J0; j < J1; ++j) {
+          ra[j] = __builtin_amdgcn_rcpf(1.f - alpha[j]);
+          T[j] = active[j] ? T[j] * ra[j] : T[j];
+          fac[j] = active[j] ? alpha[j] * T[j] : 0.f;
+          S2[j] = splat(0.f);
+        }
 #pragma unroll
-        for (int i = 0; i < QG; ++i) {
+        for (int q = 0; q < NQ; ++q) {
           float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (GEOM) c4 = crow[q0 + i];
-          c01[i] = f2{c4.x, c4.y};
-          c23[i] = f2{c4.z, c4.w};
-          a01[i] = splat(0.f);
-          a23[i] = splat(0.f);
-        }
+          if (GEOM) c4 = crow[q];
+          const f2 c01 = {c4.x, c4.y}, c23 = {c4.z, c4.w};
+          f2 a01 = splat(0.f), a23 = splat(0.f);
 #pragma unroll
-        for (int j = 0; j < PPL; ++j) {
-          if (!SLOT_SKIP || PPL == 1 || slot[j] != 0ull) {
-            const f2 f = splat(fac[j]);
-#pragma unroll
-            for (int i = 0; i < QG; ++i) {
-              if (GEOM) {
-                S2[j] = fma2(c01[i], vout[j][2 * (q0 + i)], S2[j]);
-                S2[j] = fma2(c23[i], vout[j][2 * (q0 + i) + 1], S2[j]);
-              }
-              a01[i] = fma2(f, vout[j][2 * (q0 + i)], a01[i]);
-              a23[i] = fma2(f, vout[j][2 * (q0 + i) + 1], a23[i]);
+          for (int j = J0; j < J1; ++j) {
+            if (GEOM) {
+              S2[j] = fma2(c01, vout[j][2 * q], S2[j]);
+              S2[j] = fma2(c23, vout[j][2 * q + 1], S2[j]);
             }
+            const f2 f = splat(fac[j]);
+            a01 = fma2(f, vout[j][2 * q], a01);
+            a23 = fma2(f, vout[j][2 * q + 1], a23);
           }
+          red[q * 68 + lane] = quad_fold_rows(a01[0], a01[1], a23[0], a23[1]);
         }
+        if (GEOM) {
+          float geo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // x y a b c o |x| |y|
 #pragma unroll
-        for (int i = 0; i < QG; ++i)
-          red[(q0 + i) * 68 + lane] = quad_fold_rows(a01[i][0], a01[i][1], a23[i][0], a23[i][1]);
-      }
-      if (GEOM) {
-        float geo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // x y a b c o |x| |y|
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) {
-          if (!SLOT_SKIP || PPL == 1 || slot[j] != 0ull) {
+          for (int j = J0; j < J1; ++j) {
             const int jx = j % Rg::BW, jy = j / Rg::BW;
             const float S = S2[j][0] + S2[j][1];
             const float v_alpha = S * T[j] - (Bsum[j] - W[j]) * ra[j];
@@ -281,10 +264,20 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
             geo[6] += fabsf(vx);
             geo[7] += fabsf(vy);
           }
+          red[NQ * 68 + lane] = quad_fold_rows(geo[0], geo[1], geo[2], geo[3]);
+          red[(NQ + 1) * 68 + lane] = quad_fold_rows(geo[4], geo[5], geo[6], geo[7]);
         }
-        red[NQ * 68 + lane] = quad_fold_rows(geo[0], geo[1], geo[2], geo[3]);
-        red[(NQ + 1) * 68 + lane] = quad_fold_rows(geo[4], geo[5], geo[6], geo[7]);
-      }
+      };
+      // A Gaussian that only reaches the upper or the lower half of the tile (38 % of the contributing pairs
+      // at the benchmark shape) is composited over that half's two pixel slots only: one wave-uniform branch
+      // per Gaussian.  (Finer, per-slot branches were measured slower than doing the arithmetic.)
+      using std::integral_constant;
+      if (PPL == 4 && HALF_SKIP && (slot[2 % PPL] | slot[3 % PPL]) == 0ull)
+        composite(integral_constant<int, 0>{}, integral_constant<int, PPL / 2>{});
+      else if (PPL == 4 && HALF_SKIP && (slot[0] | slot[1 % PPL]) == 0ull)
+        composite(integral_constant<int, PPL / 2>{}, integral_constant<int, PPL>{});
+      else
+        composite(integral_constant<int, 0>{}, integral_constant<int, PPL>{});
       // one lane per value: colours go to v_colors[gid, ch_off + k], the 8 geometry values to v_geom[gid, :]
 #pragma unroll
       for (int k0 = 0; k0 < NV; k0 += WAVE) {

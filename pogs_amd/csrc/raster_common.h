@@ -28,10 +28,11 @@ constexpr float T_STOP = 1e-4f;
 // apart.  With several pixels per lane the lane grid is 16 x 4 and pixel slot j of every lane lies in the
 // j-th 16x4 strip of the region, so one dx serves all of a lane's pixels.  A Gaussian that only reaches part
 // of the tile leaves whole slots without a single active lane (2.8 of 4 slots are live on average at the
-// benchmark shape); skipping such slots with wave-uniform branches was measured SLOWER than doing the
-// arithmetic (1.29 ms vs 1.24 ms backward: ~20 extra branches per Gaussian cost more issue slots than the
-// skipped FMAs), so SLOT_SKIP stays off.
-constexpr bool SLOT_SKIP = false;
+// benchmark shape).  Skipping slot by slot with wave-uniform branches was measured SLOWER than doing the
+// arithmetic (~20 extra branches per Gaussian cost more issue slots than the skipped FMAs); what pays is ONE
+// branch per Gaussian between "all four slots", "upper two" and "lower two" (HALF_SKIP) in the backward
+// kernel (-2 %); the same three-way split pushed the forward kernel to 256 registers and one wave per SIMD.
+constexpr bool HALF_SKIP = true;
 template <int TS, int PPL>
 struct Region;
 template <>
