@@ -104,12 +104,20 @@ int pr_isect_count(int C, int N, const float *means2d, const int32_t *radii, con
  * it, n_isects is only the CAPACITY of the buffers -- a caller that does not want to wait for the count
  * to reach the host sizes them from a guess, launches, and compares afterwards: if the true count is
  * larger than the capacity the outputs are incomplete (never out of bounds) and the call must be repeated.
- * Entries of flatten_ids / isect_ids past the true count are unspecified. */
+ * Entries of flatten_ids / isect_ids past the true count are unspecified.
+ * depth_order (may be NULL): the output of pr_depth_order; without it the depth sort is done here. */
 size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects, int64_t n_tiles_total);
 int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                        const float *conics, const float *opacities, const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h, int64_t n_isects,
                        int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets, int32_t *tile_order,
-                       const int64_t *n_isects_dev, void *scratch, size_t scratch_bytes, void *stream);
+                       const int64_t *n_isects_dev, const int32_t *depth_order, void *scratch,
+                       size_t scratch_bytes, void *stream);
+/* depth_order[C*N] int32: the flat indices c*N+n in stable ascending order of the depths' float bits (ties by
+ * ascending index) -- the first level of phase 2's two-level sort, split out because it depends on the
+ * projection only: a caller may run it on another stream while colours are evaluated and tiles counted. */
+size_t pr_depth_order_scratch_bytes(int C, int N);
+int pr_depth_order(int C, int N, const float *depths, int32_t *depth_order, void *scratch, size_t scratch_bytes,
+                   void *stream);
 /* isect_offsets[C,tile_h,tile_w] int32: index of the first intersection of every (camera, tile). */
 int pr_isect_offsets(int64_t n_isects, const int64_t *isect_ids, int C, int tile_w, int tile_h,
                      int32_t *isect_offsets, void *stream);

@@ -31,7 +31,9 @@ SIGNATURES = {
     "pr_isect_count": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "pr_isect_sort_scratch_bytes": (c_size_t, [c_int, c_int, c_int64, c_int64]),
     "pr_isect_emit_sort": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P,
-                                   _P, _P, _P, c_size_t, _P]),
+                                   _P, _P, _P, _P, c_size_t, _P]),
+    "pr_depth_order_scratch_bytes": (c_size_t, [c_int, c_int]),
+    "pr_depth_order": (c_int, [c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "pr_isect_offsets": (c_int, [c_int64, _P, c_int, c_int, c_int, _P, _P]),
     "pr_raster_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                               c_int64, c_int, _P, _P, _P, _P, c_int, _P]),

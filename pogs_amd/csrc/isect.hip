@@ -379,7 +379,9 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t total, const fl
                                                          uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  keys[idx] = tiles_per_gauss[idx] > 0 ? (uint32_t)__float_as_int(depths[idx]) : 0xFFFFFFFFu;
+  // Gaussians without tiles emit nothing wherever they land; pushing them to the end when the counts are
+  // known just keeps the emitting waves dense
+  keys[idx] = (!tiles_per_gauss || tiles_per_gauss[idx] > 0) ? (uint32_t)__float_as_int(depths[idx]) : 0xFFFFFFFFu;
   vals[idx] = (uint32_t)idx;
 }
 
@@ -497,11 +499,45 @@ extern "C" size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects, in
   return phase2_layout((int64_t)C * N, n_isects, n_tiles_total > 0 ? n_tiles_total : 0).total;
 }
 
+// Depth order of all C*N Gaussians on its own: depends on the projection's depths only, so a caller can run
+// it on a second stream next to the colour evaluation and the tile counting.
+extern "C" size_t pr_depth_order_scratch_bytes(int C, int N) {
+  const int64_t cn = (int64_t)C * N;
+  if (cn <= 0) return 256;
+  size_t t = 0;
+  (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, t, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                              (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)cn, 0u, 32u);
+  return align256((size_t)cn * 4) * 3 + align256(t) + 256;
+}
+
+extern "C" int pr_depth_order(int C, int N, const float *depths, int32_t *depth_order, void *scratch,
+                              size_t scratch_bytes, void *stream) {
+  if (C < 0 || N < 0) return PR_EINVAL;
+  const int64_t total = (int64_t)C * N;
+  if (total == 0) return PR_OK;
+  if (total > (int64_t)2147483647) return PR_EUNSUPPORTED;
+  if (!depths || !depth_order || !scratch) return PR_EINVAL;
+  if (scratch_bytes < pr_depth_order_scratch_bytes(C, N)) return PR_ESCRATCH;
+  char *base = (char *)scratch;
+  const size_t seg = align256((size_t)total * 4);
+  uint32_t *k_in = (uint32_t *)base, *k_out = (uint32_t *)(base + seg), *v_in = (uint32_t *)(base + 2 * seg);
+  void *temp = base + 3 * seg;
+  size_t tb = scratch_bytes - 3 * seg;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(depth_keys_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, depths,
+                     (const int32_t *)nullptr, k_in, v_in);
+  int rc = check_launch("depth_keys_kernel");
+  if (rc) return rc;
+  PR_HIP(rocprim::radix_sort_pairs<SortConfig>(temp, tb, (const uint32_t *)k_in, k_out, (const uint32_t *)v_in,
+                                               (uint32_t *)depth_order, (size_t)total, 0u, 32u, st));
+  return PR_OK;
+}
+
 extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
                                   const float *conics, const float *opacities, const int32_t *tiles_per_gauss, int tile_size, int tile_w, int tile_h,
                                   int64_t n_isects, int64_t *isect_ids, int32_t *flatten_ids,
                                   int32_t *isect_offsets, int32_t *tile_order, const int64_t *n_isects_dev,
-                                  void *scratch, size_t scratch_bytes, void *stream) {
+                                  const int32_t *depth_order, void *scratch, size_t scratch_bytes, void *stream) {
   if (C < 0 || N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0) return PR_EINVAL;
   const int64_t total = (int64_t)C * N;
   if (tile_order && !isect_offsets) return PR_EINVAL;  // the order is derived from the offsets table
@@ -538,12 +574,18 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
   void *temp = base + L.temp;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid_n = (unsigned)((total + 255) / 256);
-  hipLaunchKernelGGL(depth_keys_kernel, dim3(grid_n), dim3(256), 0, st, total, depths, tiles_per_gauss, dk_in, dv_in);
-  int rc = check_launch("depth_keys_kernel");
-  if (rc) return rc;
+  int rc = PR_OK;
   size_t tb = L.temp_bytes;
-  PR_HIP(rocprim::radix_sort_pairs<SortConfig>(temp, tb, (const uint32_t *)dk_in, dk_out, (const uint32_t *)dv_in, dv_out,
-                                   (size_t)total, 0u, 32u, st));
+  if (depth_order) {
+    dv_out = (uint32_t *)depth_order;  // computed by pr_depth_order
+  } else {
+    hipLaunchKernelGGL(depth_keys_kernel, dim3(grid_n), dim3(256), 0, st, total, depths, tiles_per_gauss, dk_in,
+                       dv_in);
+    rc = check_launch("depth_keys_kernel");
+    if (rc) return rc;
+    PR_HIP(rocprim::radix_sort_pairs<SortConfig>(temp, tb, (const uint32_t *)dk_in, dk_out, (const uint32_t *)dv_in,
+                                                 dv_out, (size_t)total, 0u, 32u, st));
+  }
   auto it = rocprim::make_transform_iterator((const uint32_t *)dv_out, TilesOf{tiles_per_gauss});
   tb = L.temp_bytes;
   PR_HIP(rocprim::exclusive_scan(temp, tb, it, starts, 0u, (size_t)total, rocprim::plus<uint32_t>(), st));

@@ -199,9 +199,37 @@ def _pinned_count(dev: torch.device) -> Tensor:
     return t
 
 
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _depth_order_async(depths: Tensor):
+    """Start the depth sort of all C*N Gaussians on a second stream and return (order, event): it needs the
+    projection's depths only, so it runs next to the colour evaluation and the tile counting instead of in
+    front of the emission (four small radix passes that leave most of the GPU idle when run alone)."""
+    lib = _lib.load()
+    dev = depths.device
+    C, N = depths.shape
+    main = torch.cuda.current_stream(dev)
+    side = _side_streams.get(dev.index)
+    if side is None:
+        side = _side_streams[dev.index] = torch.cuda.Stream(dev)
+    depths = depths.detach().contiguous()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        order = torch.empty(C * N, dtype=torch.int32, device=dev)
+        nb = lib.pr_depth_order_scratch_bytes(C, N)
+        scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+        _call("pr_depth_order", C, N, _ptr(depths), _ptr(order), _ptr(scratch), nb, side.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(side)
+    depths.record_stream(side)
+    order.record_stream(main)
+    return order, done
+
+
 def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int, tile_height: int,
                want_ids: bool, want_offsets: bool, want_order: bool = False, conics: Optional[Tensor] = None,
-               opacities: Optional[Tensor] = None):
+               opacities: Optional[Tensor] = None, depth_order=None):
     """Tile binning: -> tiles_per_gauss [C,N] int32, isect_ids [I] int64 or None, flatten_ids [I] int32,
     isect_offsets [C,th,tw] int32 or None[, tile_order [C*th*tw] int32 or None when ``want_order``: tiles
     sorted by list length, longest first (None below ``_ORDER_MIN_TILES`` tiles)].
@@ -234,6 +262,11 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
         _call("pr_isect_count", C, N, _ptr(means2d), _ptr(radii), _ptr(conics), _ptr(opacities), tile_size,
               tile_width, tile_height, _ptr(tiles_per_gauss), _ptr(cum), _ptr(scratch), nb, _stream())
 
+        order_ptr = None
+        if depth_order is not None:     # (order, event) of _depth_order_async: the emission waits for it
+            torch.cuda.current_stream(dev).wait_event(depth_order[1])
+            order_ptr = depth_order[0].data_ptr()
+
         def emit(capacity, count_on_device):
             ids = torch.empty(capacity, dtype=torch.int64, device=dev) if want_ids else None
             flat = torch.empty(capacity, dtype=torch.int32, device=dev)
@@ -242,7 +275,7 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
             scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
             _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(conics),
                   _ptr(opacities), _ptr(tiles_per_gauss), tile_size, tile_width, tile_height, capacity, _ptr(ids), _ptr(flat), _ptr(offsets), _ptr(order),
-                  cum[-1:].data_ptr() if count_on_device else None, _ptr(scratch), nb, _stream())
+                  cum[-1:].data_ptr() if count_on_device else None, order_ptr, _ptr(scratch), nb, _stream())
             return ids, flat
 
         # The intersection count sizes the lists.  Waiting for it on the host leaves the GPU idle for the
@@ -577,6 +610,7 @@ def rasterization(
     radii, means2d, depths, conics, compensations = fully_fused_projection(
         means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
         calc_compensations=(rasterize_mode == "antialiased"))
+    depth_order = _depth_order_async(depths) if C * N > 0 else None
     opac = opacities[None, :].expand(C, N)
     if compensations is not None:
         opac = opac * compensations
@@ -618,7 +652,7 @@ def rasterization(
     # compositor lists: only the (Gaussian, tile) pairs that can contribute
     _, _, flatten_ids, isect_offsets, tile_order = _bin_tiles(
         means2d, radii, depths, tile_size, tile_width, tile_height, False, True, True, conics=conics,
-        opacities=opac)
+        opacities=opac, depth_order=depth_order)
 
     # expected depth (ED): the depth channel is divided by max(alpha, 1e-10) inside the kernels
     ed_channel = n_channels - 1 if render_mode in ("ED", "RGB+ED") else -1

@@ -256,6 +256,18 @@ def test_footprint_tested_lists_drop_only_pairs_that_cannot_contribute(gpu, tile
     assert dropped > 0
 
 
+def test_depth_order_is_the_stable_sort_of_the_depth_bits(gpu):
+    rd = _rendering()
+    g = torch.Generator().manual_seed(0)
+    depths = (torch.rand(2, 70001, generator=g) * 30 + 0.1).to(gpu)
+    depths[0, 100:300] = depths[0, 5]          # ties resolve by ascending flat index
+    depths[1, ::7] = 0.0                        # culled entries are written as zeros by the projection
+    order, done = rd._depth_order_async(depths)
+    done.synchronize()
+    ref = torch.sort(depths.flatten().view(torch.int32), stable=True).indices
+    assert torch.equal(order.long(), ref)
+
+
 def test_isect_empty(gpu):
     rd = _rendering()
     means2d = torch.zeros(1, 10, 2, device=gpu)
