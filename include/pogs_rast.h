@@ -98,8 +98,9 @@ int pr_isect_count(int C, int N, const float *means2d, const int32_t *radii, con
  * materialised for callers that want gsplat's `isect_ids`); isect_offsets[C,tile_h,tile_w] int32 (may be
  * NULL), the same table pr_isect_offsets derives from isect_ids, written here straight from the sorted
  * tile keys; tile_order[C*tile_h*tile_w] int32 (may be NULL; needs isect_offsets), the flat tile indices
- * sorted by list length, longest first -- the launch order pr_raster_fwd/bwd accept.
- * n_tiles_total = C*tile_h*tile_w when tile_order is wanted, else 0.
+ * ordered by list length, longest first up to a bucket of 1/1024 of the longest list -- the launch order
+ * pr_raster_fwd/bwd accept.  n_tiles_total = C*tile_h*tile_w when tile_order is wanted, else 0 (reserved:
+ * the order needs no scratch at present).
  * n_isects_dev (may be NULL): device pointer to the true intersection count (cum_tiles + C*N - 1).  With
  * it, n_isects is only the CAPACITY of the buffers -- a caller that does not want to wait for the count
  * to reach the host sizes them from a guess, launches, and compares afterwards: if the true count is

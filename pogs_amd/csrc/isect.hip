@@ -329,8 +329,7 @@ using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::
                                               rocprim::default_config, 512 * 1024>;
 
 struct Phase2Layout {
-  size_t dkeys_in, dkeys_out, dvals_in, dvals_out, starts, tkeys_in, tkeys_out, tvals_in, lkeys_in, lkeys_out,
-      lvals_in, temp, temp_bytes, total;
+  size_t dkeys_in, dkeys_out, dvals_in, dvals_out, starts, tkeys_in, tkeys_out, tvals_in, temp, temp_bytes, total;
 };
 
 struct TilesOf {
@@ -338,7 +337,7 @@ struct TilesOf {
   __device__ __host__ uint32_t operator()(uint32_t flat) const { return (uint32_t)tpg[flat]; }
 };
 
-static Phase2Layout phase2_layout(int64_t cn, int64_t n_isects, int64_t n_tiles) {
+static Phase2Layout phase2_layout(int64_t cn, int64_t n_isects) {
   Phase2Layout L;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -354,21 +353,14 @@ static Phase2Layout phase2_layout(int64_t cn, int64_t n_isects, int64_t n_tiles)
   L.tkeys_in = take((size_t)n_isects * 4);
   L.tkeys_out = take((size_t)n_isects * 4);
   L.tvals_in = take((size_t)n_isects * 4);
-  L.lkeys_in = take((size_t)n_tiles * 4);
-  L.lkeys_out = take((size_t)n_tiles * 4);
-  L.lvals_in = take((size_t)n_tiles * 4);
-  size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+  size_t t1 = 0, t2 = 0, t3 = 0;
   (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                   (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)cn, 0u, 32u);
   (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, t2, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                   (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n_isects, 0u, 32u);
   auto it = rocprim::make_transform_iterator((const uint32_t *)nullptr, TilesOf{nullptr});
   (void)rocprim::exclusive_scan(nullptr, t3, it, (uint32_t *)nullptr, 0u, (size_t)cn, rocprim::plus<uint32_t>());
-  if (n_tiles > 0)
-    (void)rocprim::radix_sort_pairs_desc(nullptr, t4, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                         (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n_tiles, 0u, 32u);
   L.temp_bytes = t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3);
-  if (t4 > L.temp_bytes) L.temp_bytes = t4;
   L.temp = take(L.temp_bytes);
   L.total = off + 256;
   return L;
@@ -470,17 +462,50 @@ __global__ void __launch_bounds__(256) tile_offsets_kernel(int64_t cap, const in
     for (int t = cur + 1; t < n_tiles_total; ++t) offsets[t] = (int32_t)n_isects;
 }
 
-// Sort keys for the launch order of the compositing kernels: the length of every tile's list.
-__global__ void __launch_bounds__(256) tile_length_kernel(int n_tiles_total, const int32_t *__restrict__ offsets,
+// Launch order of the compositing kernels: tiles by list length, longest first.  Only the rough order
+// matters (it shortens the tail of the launch), so one workgroup buckets the tiles by length -- 1024 linear
+// buckets between 0 and the longest list -- instead of a full device sort (six small kernels for ~8k keys).
+__global__ void __launch_bounds__(1024) tile_order_kernel(int n_tiles_total, const int32_t *__restrict__ offsets,
                                                           int64_t cap, const int64_t *__restrict__ n_dev,
-                                                          uint32_t *__restrict__ keys,
-                                                          uint32_t *__restrict__ vals) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_tiles_total) return;
+                                                          int32_t *__restrict__ order) {
+  constexpr int NB = 1024;
+  __shared__ int bucket[NB];
+  __shared__ int wave_part[16];
+  __shared__ int longest;
+  const int tid = threadIdx.x;
   const int64_t n_isects = true_count(cap, n_dev);
-  const int32_t hi = t + 1 < n_tiles_total ? offsets[t + 1] : (int32_t)n_isects;
-  keys[t] = (uint32_t)(hi - offsets[t]);
-  vals[t] = (uint32_t)t;
+  auto length = [&](int t) {
+    const int32_t hi = t + 1 < n_tiles_total ? offsets[t + 1] : (int32_t)n_isects;
+    return hi - offsets[t];
+  };
+  bucket[tid] = 0;
+  if (tid == 0) longest = 0;
+  __syncthreads();
+  int mx = 0;
+  for (int t = tid; t < n_tiles_total; t += NB) mx = max(mx, length(t));
+  atomicMax(&longest, mx);
+  __syncthreads();
+  const float scale = longest > 0 ? (float)(NB - 1) / (float)longest : 0.f;
+  for (int t = tid; t < n_tiles_total; t += NB) atomicAdd(&bucket[(int)((float)(longest - length(t)) * scale)], 1);
+  __syncthreads();
+  // exclusive scan of the 1024 bucket sizes: one value per thread
+  const int lane = tid & 63, wave = tid >> 6;
+  const int mine = bucket[tid];
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d);
+    if (lane >= d) incl += up;
+  }
+  if (lane == 63) wave_part[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wave_part[w];
+  __syncthreads();
+  bucket[tid] = base + incl - mine;  // from here on: the bucket's write cursor
+  __syncthreads();
+  for (int t = tid; t < n_tiles_total; t += NB)
+    order[atomicAdd(&bucket[(int)((float)(longest - length(t)) * scale)], 1)] = t;
 }
 
 __global__ void __launch_bounds__(256) isect_ids_kernel(int64_t cap, const int64_t *__restrict__ n_dev,
@@ -496,7 +521,8 @@ __global__ void __launch_bounds__(256) isect_ids_kernel(int64_t cap, const int64
 
 extern "C" size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects, int64_t n_tiles_total) {
   if (n_isects <= 0 || (int64_t)C * N <= 0) return 256;
-  return phase2_layout((int64_t)C * N, n_isects, n_tiles_total > 0 ? n_tiles_total : 0).total;
+  (void)n_tiles_total;
+  return phase2_layout((int64_t)C * N, n_isects).total;
 }
 
 // Depth order of all C*N Gaussians on its own: depends on the projection's depths only, so a caller can run
@@ -548,12 +574,9 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
     if (isect_offsets && n_tiles_total > 0) {
       PR_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)n_tiles_total * 4, (hipStream_t)stream));
       if (tile_order) {
-        if (!scratch || scratch_bytes < (size_t)n_tiles_total * 8) return PR_ESCRATCH;
-        uint32_t *k = (uint32_t *)scratch;  // all lengths are zero: the identity order
-        hipLaunchKernelGGL(tile_length_kernel, dim3((unsigned)((n_tiles_total + 255) / 256)), dim3(256), 0,
-                           (hipStream_t)stream, (int)n_tiles_total, isect_offsets, (int64_t)0,
-                           (const int64_t *)nullptr, k, (uint32_t *)tile_order);
-        return check_launch("tile_length_kernel");
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (int)n_tiles_total,
+                           isect_offsets, (int64_t)0, (const int64_t *)nullptr, tile_order);
+        return check_launch("tile_order_kernel");
       }
     }
     return PR_OK;
@@ -563,7 +586,7 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
   const int tile_bits = bit_length((int64_t)tile_w * tile_h);
   const int cam_bits = bit_length((int64_t)C - 1);
   if (tile_bits + cam_bits > 32) return PR_EUNSUPPORTED;
-  const Phase2Layout L = phase2_layout(total, n_isects, tile_order ? n_tiles_total : 0);
+  const Phase2Layout L = phase2_layout(total, n_isects);
   if (L.total > scratch_bytes) return PR_ESCRATCH;
   char *base = (char *)scratch;
   uint32_t *dk_in = (uint32_t *)(base + L.dkeys_in), *dk_out = (uint32_t *)(base + L.dkeys_out);
@@ -615,16 +638,10 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
     if (rc) return rc;
   }
   if (tile_order) {
-    uint32_t *lk_in = (uint32_t *)(base + L.lkeys_in), *lk_out = (uint32_t *)(base + L.lkeys_out);
-    uint32_t *lv_in = (uint32_t *)(base + L.lvals_in);
-    hipLaunchKernelGGL(tile_length_kernel, dim3((unsigned)((n_tiles_total + 255) / 256)), dim3(256), 0, st,
-                       (int)n_tiles_total, isect_offsets, n_isects, n_isects_dev, lk_in, lv_in);
-    rc = check_launch("tile_length_kernel");
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, (int)n_tiles_total, isect_offsets, n_isects,
+                       n_isects_dev, tile_order);
+    rc = check_launch("tile_order_kernel");
     if (rc) return rc;
-    tb = L.temp_bytes;
-    PR_HIP(rocprim::radix_sort_pairs_desc(temp, tb, (const uint32_t *)lk_in, lk_out, (const uint32_t *)lv_in,
-                                          (uint32_t *)tile_order, (size_t)n_tiles_total, 0u,
-                                          (unsigned)bit_length(n_isects), st));
   }
   if (isect_ids) {
     hipLaunchKernelGGL(isect_ids_kernel, dim3(grid_i), dim3(256), 0, st, n_isects, n_isects_dev, tk_out, flatten_ids, depths,

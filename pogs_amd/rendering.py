@@ -270,8 +270,7 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
         def emit(capacity, count_on_device):
             ids = torch.empty(capacity, dtype=torch.int64, device=dev) if want_ids else None
             flat = torch.empty(capacity, dtype=torch.int32, device=dev)
-            nb = max(lib.pr_isect_sort_scratch_bytes(C, N, capacity, n_tiles if order is not None else 0),
-                     8 * n_tiles if order is not None else 0)
+            nb = lib.pr_isect_sort_scratch_bytes(C, N, capacity, n_tiles if order is not None else 0)
             scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
             _call("pr_isect_emit_sort", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(conics),
                   _ptr(opacities), _ptr(tiles_per_gauss), tile_size, tile_width, tile_height, capacity, _ptr(ids), _ptr(flat), _ptr(offsets), _ptr(order),
