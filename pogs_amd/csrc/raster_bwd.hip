@@ -176,17 +176,21 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
         dy[i] = g.y - (py0 + (float)(i * Rg::SY));
         cdy2[i] = h.y * dy[i] * dy[i];
       }
-      float e[PPL], alpha[PPL];
-      bool active[PPL];
+      // e = exp(-sigma), ar = opacity * e, alpha = the alpha this pixel composited with, or 0 when the Gaussian
+      // did not contribute to it.  Everything downstream is arithmetic on alpha (an alpha of 0 gives ra = 1,
+      // fac = 0 and leaves T untouched exactly), so no per-pixel flags are carried through the loop body.
+      float e[PPL], ar[PPL], alpha[PPL];
       unsigned long long slot[PPL], any = 0ull;  // per pixel slot: the lanes with an active pixel
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
         const int jx = j % Rg::BW, jy = j / Rg::BW;
         const float power = adx2[jx] + cdy2[jy] + bdx[jx] * dy[jy];
         e[j] = __builtin_amdgcn_exp2f(power);
-        alpha[j] = fminf(ALPHA_MAX, g.z * e[j]);
-        active[j] = (power <= 0.f) && (alpha[j] >= ALPHA_MIN) && (idx < last[j]);
-        slot[j] = __builtin_amdgcn_ballot_w64(active[j]);
+        ar[j] = g.z * e[j];
+        const float a = fminf(ALPHA_MAX, ar[j]);
+        const bool active = (power <= 0.f) && (a >= ALPHA_MIN) && (idx < last[j]);
+        alpha[j] = active ? a : 0.f;
+        slot[j] = __builtin_amdgcn_ballot_w64(active);
         any |= slot[j];
       }
       if (any == 0ull) continue;
@@ -218,8 +222,8 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
 #pragma unroll
         for (int j = J0; j < J1; ++j) {
           ra[j] = __builtin_amdgcn_rcpf(1.f - alpha[j]);
-          T[j] = active[j] ? T[j] * ra[j] : T[j];
-          fac[j] = active[j] ? alpha[j] * T[j] : 0.f;
+          T[j] *= ra[j];
+          fac[j] = alpha[j] * T[j];
           S2[j] = splat(0.f);
         }
 #pragma unroll
@@ -248,10 +252,10 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
             const float S = S2[j][0] + S2[j][1];
             const float v_alpha = S * T[j] - (Bsum[j] - W[j]) * ra[j];
             Bsum[j] = fmaf(fac[j], S, Bsum[j]);
-            const float ar = g.z * e[j];
-            const bool gr = active[j] && (ar <= ALPHA_MAX);
-            const float vs = gr ? -ar * v_alpha : 0.f;  // d loss / d sigma
-            geo[5] += gr ? e[j] * v_alpha : 0.f;
+            // the exponential passes a gradient on when the pixel took this Gaussian at its unclamped alpha
+            const float ev = (alpha[j] == ar[j] ? e[j] : 0.f) * v_alpha;
+            geo[5] += ev;                    // d loss / d opacity
+            const float vs = -g.z * ev;      // d loss / d sigma
             const float t1 = vs * dx[jx], t2 = vs * dy[jy];
             geo[2] = fmaf(t1, dx[jx], geo[2]);
             geo[3] = fmaf(t1, dy[jy], geo[3]);
@@ -285,8 +289,10 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
         if (k < NV) {
           const float4 *src = own + k0 / 4 * 17;  // 64 values further = 16 quads = 16*68 floats
           const float4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
-          const float v = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w)) +
-                          (((p2.x + p2.y) + (p2.z + p2.w)) + ((p3.x + p3.y) + (p3.z + p3.w)));
+          const f2 s0 = f2{p0.x, p0.y} + f2{p0.z, p0.w}, s1 = f2{p1.x, p1.y} + f2{p1.z, p1.w};
+          const f2 s2 = f2{p2.x, p2.y} + f2{p2.z, p2.w}, s3 = f2{p3.x, p3.y} + f2{p3.z, p3.w};
+          const f2 u = (s0 + s1) + (s2 + s3);
+          const float v = u[0] + u[1];
           if (k < CDP) {
             float *dst = gcol[k0 / WAVE];
             if (dst) atomic_add_noret(dst + (int64_t)(gshared[k0 / WAVE] ? gid - cam_first : gid) * gld[k0 / WAVE], v);
