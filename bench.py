@@ -42,8 +42,9 @@ def stage_bytes(N, C, I, P, K, F, D, key_bits):
         "pr_project_fwd": cn * (44 + 28),
         "pr_sh_fwd": cn * (12 * K + 12),
         "pr_isect_count": 0,
-        "pr_isect_emit_sort": I * (12 + 24 * s),
-        "pr_isect_offsets": I * 8,
+        # the two-level sort is priced as the reference's one sort: its bytes are charged to the second level
+        "pr_depth_order": 0,
+        "pr_isect_emit_sort": I * (12 + 24 * s) + I * 8,   # incl. the offsets table (formerly pr_isect_offsets)
         "pr_raster_fwd": I * (28 + 4 * D) + P * (4 * D + 8),
         "pr_raster_bwd": I * (28 + 4 * D) + I * (32 + 4 * D) + P * (4 * D + 12),
         "pr_project_bwd": cn * (28 + 44 + 44),
@@ -212,7 +213,7 @@ def main():
         per_stage, total_bytes = stage_bytes(N, 1, I, H * W, 16, F, D, key_bits)
         summ = timer.summary()
         stages = {k: v[1] / max(v[0], 1) * (v[0] / args.steps) for k, v in summ.items()}  # ms per step
-        dom = max(stages, key=stages.get)
+        dom = max((k for k in stages if per_stage.get(k, 0) > 0), key=stages.get)
         launches, total_ms = summ[dom]
         avg_ms = total_ms / launches
         dom_bytes = per_stage[dom] / (launches / args.steps)
