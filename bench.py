@@ -128,17 +128,28 @@ def main():
                     help="render RGB+ED and the features as two gsplat-signature calls instead of one fused call")
     args = ap.parse_args()
 
+    if os.environ.get("POGS_BENCH_HANG_DUMP"):   # debugging aid: dump every thread's stack after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["POGS_BENCH_HANG_DUMP"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    dev = torch.device("cuda", local_rank)
+    # one GPU per rank; POGS_BENCH_SHARE_GPU=1 lets the ranks of a rehearsal share the devices that exist
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and os.environ.get("POGS_BENCH_SHARE_GPU") != "1":
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {n_dev} device(s)")
+    dev = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("POGS_BENCH_BACKEND", "nccl")   # "gloo" for a rehearsal on a shared GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     N, W, H, F, ts = args.gaussians, args.width, args.height, args.features, args.tile_size
     sc = make_scene(N, W, H, n_features=F, n_views=max(world, 1), seed=0)

@@ -49,6 +49,13 @@ class FlatGrads:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
             return None
         if dist.get_backend(group) == "gloo":  # gloo has no AVG
+            if self.flat.is_cuda:
+                # rehearsal on GPUs without RCCL: stage through the host explicitly (gloo's own handling of large
+                # device tensors was seen to hang when two ranks share one GPU)
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                self.flat.copy_(host.div_(dist.get_world_size(group)))
+                return None
             work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
             if async_op:
                 return work
