@@ -27,7 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from pogs_amd import rendering  # noqa: E402
-from pogs_amd.dist import FlatGrads  # noqa: E402
+from pogs_amd.dist import GradExchange  # noqa: E402
 from pogs_amd.scenes import make_scene  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E nominal
@@ -163,7 +163,7 @@ def main():
     K = sc.Ks[view:view + 1].to(dev).contiguous()
     # Multi-GPU: every .grad aliases one flat buffer that is mean-all-reduced each step.  Single GPU: plain
     # zero_grad(set_to_none=True) semantics, as the reference's trainer does between iterations.
-    grads = FlatGrads(params.values()) if world > 1 else None
+    grads = GradExchange(params.values()) if world > 1 else None
     D = 3 + F + 1
     g = torch.Generator().manual_seed(100 + rank)
     v_colors = torch.randn(1, H, W, D, generator=g).to(dev)
@@ -171,11 +171,8 @@ def main():
     info = {}
 
     def step():
-        if grads is not None:
-            grads.zero_()
-        else:
-            for p in params.values():
-                p.grad = None
+        for p in params.values():   # autograd adopts the gradient tensors the kernels produce
+            p.grad = None
         scales = torch.exp(params["log_scales"])
         opac = torch.sigmoid(params["opacity_logits"])
         common = dict(means=params["means"], quats=params["quats"], scales=scales, opacities=opac, viewmats=viewmat,
@@ -253,7 +250,7 @@ def main():
                              "fwd+bwd, absgrad, tile %d, 1 view per GPU%s" % (
                                  N, W, H, F, ts, ", fused single call" if not args.two_call else ", two calls")),
                 "gaussians": N, "width": W, "height": H, "channels": D, "n_isects": I, "n_isects_composited": I_walked,
-                "parallelism": "camera-sharded dp%d, flat-gradient mean all-reduce (%.0f MB)" % (
+                "parallelism": "camera-sharded dp%d, in-place gradient mean all-reduce (%.0f MB: SH, features, packed rest)" % (
                     world, (grads.nbytes() if grads is not None else 0) / 1e6) if world > 1 else "single GPU",
             },
             "roofline": {

@@ -67,6 +67,74 @@ class FlatGrads:
         return self.flat.numel() * self.flat.element_size()
 
 
+class GradExchange:
+    """Mean all-reduce of the gradients WHERE AUTOGRAD LEFT THEM: no flat copy, no zero-fill + accumulate.
+
+    With ``FlatGrads`` every backward pass accumulates into pre-zeroed views (one fill and one read-modify-write
+    of every gradient per step); here ``.grad`` may be ``None`` before the backward pass, so autograd simply
+    adopts the tensors the kernels produced.  Large gradients (SH coefficients, features) are then reduced
+    in place, one collective each; the small ones (means, quaternions, scales, opacities) are packed into
+    one persistent buffer so that they cost one collective, not four latencies."""
+
+    def __init__(self, params: Iterable[Tensor], big_bytes: int = 32 << 20):
+        self.params: List[Tensor] = [p for p in params if p.requires_grad]
+        assert self.params, "no parameter requires grad"
+        self.big = [p for p in self.params if p.numel() * p.element_size() >= big_bytes]
+        self.small = [p for p in self.params if p.numel() * p.element_size() < big_bytes]
+        n_small = sum(p.numel() for p in self.small)
+        ref = self.params[0]
+        self.pack = torch.empty(n_small, dtype=ref.dtype, device=ref.device) if n_small else None
+
+    def nbytes(self) -> int:
+        return sum(p.numel() * p.element_size() for p in self.params)
+
+    @staticmethod
+    def _reduce(t: Tensor, group, world: int):
+        backend = dist.get_backend(group)
+        if backend == "gloo":  # no AVG; device tensors are staged through the host (rehearsals only)
+            host = t.cpu() if t.is_cuda else t
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            host.div_(world)
+            if t.is_cuda:
+                t.copy_(host)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=True)
+
+    def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None) -> None:
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        world = dist.get_world_size(group)
+        works = []
+        for p in self.big:
+            if p.grad is None:          # this rank's view did not reach the parameter: it contributes zeros
+                p.grad = torch.zeros_like(p)
+            elif not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+            works.append(self._reduce(p.grad, group, world))
+        if self.pack is not None:
+            at = 0
+            for p in self.small:
+                seg = self.pack[at:at + p.numel()]
+                if p.grad is None:
+                    seg.zero_()
+                else:
+                    seg.copy_(p.grad.reshape(-1))
+                at += p.numel()
+            works.append(self._reduce(self.pack, group, world))
+        for w in works:
+            if w is not None:
+                w.wait()
+        if self.pack is not None:
+            at = 0
+            for p in self.small:
+                seg = self.pack[at:at + p.numel()].view_as(p)
+                if p.grad is None or not p.grad.is_contiguous():
+                    p.grad = seg.clone()
+                else:
+                    p.grad.copy_(seg)
+                at += p.numel()
+
+
 def view_for_rank(n_views: int, rank: int, world: int) -> List[int]:
     """Views of a batch handled by this rank: view v -> rank v mod world."""
     return [v for v in range(n_views) if v % world == rank]

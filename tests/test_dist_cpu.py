@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from pogs_amd.dist import FlatGrads, sharded_step, view_for_rank
+from pogs_amd.dist import FlatGrads, GradExchange, sharded_step, view_for_rank
 from tests._util import small_scene
 
 
@@ -54,6 +54,47 @@ def _worker(rank, world, port, n_views, ret):
         ret.put({k: v.grad.clone() for k, v in p.items()})
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _exchange_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    shapes = dict(big_a=(300, 16, 3), small_a=(300, 3), small_b=(300,), big_b=(300, 32), unused=(300, 4))
+    base = {k: torch.randn(s, generator=g, dtype=torch.float64) for k, s in shapes.items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+    ex = GradExchange(params.values(), big_bytes=300 * 32 * 8)     # big_a and big_b reduce in place
+    assert [p.shape for p in ex.big] == [params["big_a"].shape, params["big_b"].shape]
+    for k, p in params.items():
+        if k == "unused" and rank == 1:
+            continue                                                # this rank never reaches the parameter
+        p.grad = base[k] * (rank + 1)                               # rank r contributes (r+1) * base
+    params["small_a"].grad = params["small_a"].grad.t().contiguous().t()   # a non-contiguous gradient
+    ex.all_reduce_mean()
+    if rank == 0:
+        ret.put({k: p.grad.clone() for k, p in params.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_in_place_gradient_exchange_averages_over_ranks():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = ret.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(5)
+    shapes = dict(big_a=(300, 16, 3), small_a=(300, 3), small_b=(300,), big_b=(300, 32), unused=(300, 4))
+    base = {k: torch.randn(s, generator=g, dtype=torch.float64) for k, s in shapes.items()}
+    for k, v in got.items():
+        want = base[k] * (0.5 if k == "unused" else 1.5)            # mean of 1x and 2x (or of 1x and nothing)
+        assert torch.allclose(v, want, atol=1e-12), k
 
 
 @pytest.mark.parametrize("n_views", [2, 3])
