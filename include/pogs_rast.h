@@ -190,6 +190,23 @@ int pr_rigid_bwd(int64_t N, int G, const float *init_p2ws, const float *p_deltas
                  const float *means, const float *quats, const float *v_means_out, const float *v_quats_out,
                  float *v_p_deltas, void *stream);
 
+/* ---- fused Adam over parameter groups (the step between the gradient exchange and the next forward) ------
+ * Replaces the per-group torch.optim.Adam(lr, eps=1e-15).step() calls issued through nerfstudio's
+ * Optimizers.optimizer_scaler_step_some (nerfstudio/engine/optimizers.py:159-172; trainer.py:494-510 decides
+ * which groups are due under their gradient-accumulation periods; groups and rates: pogs/pogs_config.py:38-85).
+ * Arithmetic of torch.optim.Adam without weight decay / amsgrad / maximize.  All groups passed are updated in
+ * one launch.  step = the group's update count INCLUDING this one (>= 1); lr = the rate after its scheduler.
+ * Pointers must be 16-byte aligned; param/exp_avg/exp_avg_sq are updated in place. */
+typedef struct {
+  float *param;
+  const float *grad;
+  float *exp_avg, *exp_avg_sq;
+  int64_t numel, step;
+  double lr, beta1, beta2, eps;
+} pr_adam_group;
+int pr_adam_max_groups(void);
+int pr_adam_step(const pr_adam_group *groups, int n_groups, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

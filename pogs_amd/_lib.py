@@ -39,6 +39,8 @@ SIGNATURES = {
                               c_int64, c_int, _P, _P, _P, _P, c_int, _P]),
     "pr_raster_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                               c_int64, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "pr_adam_max_groups": (c_int, []),
+    "pr_adam_step": (c_int, [_P, c_int, _P]),
     "pr_rigid_fwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pr_rigid_bwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
@@ -49,6 +51,13 @@ class Segment(ctypes.Structure):
     """pr_color_segment / pr_grad_segment (same layout): one of up to three tensors that together supply the
     composited channels."""
     _fields_ = [("ptr", ctypes.c_void_p), ("width", c_int), ("ld", c_int), ("shared", c_int)]
+
+
+class AdamGroup(ctypes.Structure):
+    """pr_adam_group."""
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("numel", c_int64), ("step", c_int64), ("lr", ctypes.c_double),
+                ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double)]
 
 
 def segment_array(items):
