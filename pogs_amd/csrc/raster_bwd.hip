@@ -153,11 +153,15 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
   const float rx0 = (float)(tx * TS) + 0.5f, ry0 = (float)(ty * TS + sub * Rg::RH) + 0.5f;
   const float rx1 = (float)min(tx * TS + TS, width) - 0.5f;
   const float ry1 = (float)min(ty * TS + sub * Rg::RH + Rg::RH, height) - 0.5f;
+  BatchGeometry pre = prefetch_batch(lane, max(range_lo, max_last - WAVE), max_last - max(range_lo, max_last - WAVE),
+                                     flatten_ids, means2d, conics, opacities);
   for (int bend = max_last; bend > range_lo; bend -= WAVE) {
     const int first = max(range_lo, bend - WAVE);
-    const int count = bend - first;
-    unsigned long long todo = stage_batch<CD>(L, lane, first, count, flatten_ids, means2d, conics, opacities,
-                                              cs, N, D, ch_off, rx0, ry0, rx1, ry1);
+    unsigned long long todo = stage_batch<CD>(L, lane, pre, cs, N, D, ch_off, rx0, ry0, rx1, ry1);
+    {  // the next batch's geometry travels while this one is composited
+      const int nend = bend - WAVE, nfirst = max(range_lo, nend - WAVE);
+      pre = prefetch_batch(lane, nfirst, nend - nfirst, flatten_ids, means2d, conics, opacities);
+    }
     while (todo) {
       const int t = 63 - __builtin_clzll(todo);
       todo &= ~(1ull << t);

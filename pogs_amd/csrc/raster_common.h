@@ -137,20 +137,46 @@ inline int make_grad_segs(float *v_colors, int D, const pr_grad_segment *segment
   return make_segs(v_colors, D, segments, n_segments, true, true, out);
 }
 
-// Stage up to 64 intersections [first, first+count) of the sorted list: lane j loads Gaussian j.
-// Returns the wave-wide mask of staged Gaussians whose footprint reaches the region.
+// The geometry of one batch of up to 64 intersections, one per lane, loaded ahead of time: the ids and the
+// records they point to are two dependent global round trips, which the caller issues a whole batch early
+// (right after staging the previous one) so that only the colour rows remain to be fetched at staging time.
+struct BatchGeometry {
+  int g;  // flat Gaussian index, -1 beyond the batch
+  float2 xy;
+  float ca, cb, cc, o;
+};
+__device__ __forceinline__ BatchGeometry prefetch_batch(int lane, int first, int count,
+                                                        const int32_t *__restrict__ flatten_ids,
+                                                        const float *__restrict__ means2d,
+                                                        const float *__restrict__ conics,
+                                                        const float *__restrict__ opacities) {
+  BatchGeometry b;
+  b.g = -1;
+  b.xy = make_float2(0.f, 0.f);
+  b.ca = b.cb = b.cc = b.o = 0.f;
+  if (lane < count) {
+    b.g = flatten_ids[first + lane];
+    b.xy = *reinterpret_cast<const float2 *>(means2d + 2 * (int64_t)b.g);
+    b.ca = conics[3 * (int64_t)b.g];
+    b.cb = conics[3 * (int64_t)b.g + 1];
+    b.cc = conics[3 * (int64_t)b.g + 2];
+    b.o = opacities[b.g];
+  }
+  return b;
+}
+
+// Stage a prefetched batch: lane j tests Gaussian j against the region and, if it can contribute, writes its
+// record and colour row to the wave's LDS slice.  Returns the wave-wide mask of staged Gaussians.
 template <int CD>
 __device__ __forceinline__ unsigned long long stage_batch(
-    WaveLds<CD> &L, int lane, int first, int count, const int32_t *__restrict__ flatten_ids,
-    const float *__restrict__ means2d, const float *__restrict__ conics, const float *__restrict__ opacities,
-    const ColorSegs &cs, int N, int D, int ch_off, float rx0, float ry0, float rx1, float ry1) {
+    WaveLds<CD> &L, int lane, const BatchGeometry &pre, const ColorSegs &cs, int N, int D, int ch_off, float rx0,
+    float ry0, float rx1, float ry1) {
   constexpr int ROW = color_row(CD);
   bool keep = false;
-  if (lane < count) {
-    int g = flatten_ids[first + lane];
-    float2 xy = *reinterpret_cast<const float2 *>(means2d + 2 * (int64_t)g);
-    float ca = conics[3 * (int64_t)g], cb = conics[3 * (int64_t)g + 1], cc = conics[3 * (int64_t)g + 2];
-    float o = opacities[g];
+  if (pre.g >= 0) {
+    const int g = pre.g;
+    const float2 xy = pre.xy;
+    const float ca = pre.ca, cb = pre.cb, cc = pre.cc, o = pre.o;
     keep = touches_region(xy.x, xy.y, o, ca, cb, cc, rx0, ry0, rx1, ry1);
     if (keep) {
       L.g4[lane] = make_float4(xy.x, xy.y, o, -0.5f * LOG2E * ca);

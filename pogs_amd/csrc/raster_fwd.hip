@@ -56,10 +56,13 @@ __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
   const float rx1 = (float)min(tx * TS + TS, width) - 0.5f;
   const float ry1 = (float)min(ty * TS + sub * Rg::RH + Rg::RH, height) - 0.5f;
   bool all_done = false;
+  BatchGeometry pre = prefetch_batch(lane, range_lo, min(WAVE, range_hi - range_lo), flatten_ids, means2d, conics,
+                                     opacities);
   for (int first = range_lo; first < range_hi && !all_done; first += WAVE) {
-    const int count = min(WAVE, range_hi - first);
-    unsigned long long todo = stage_batch<CD>(L, lane, first, count, flatten_ids, means2d, conics, opacities,
-                                              cs, N, D, ch_off, rx0, ry0, rx1, ry1);
+    unsigned long long todo = stage_batch<CD>(L, lane, pre, cs, N, D, ch_off, rx0, ry0, rx1, ry1);
+    // the next batch's geometry travels while this one is composited
+    pre = prefetch_batch(lane, first + WAVE, min(WAVE, range_hi - first - WAVE), flatten_ids, means2d, conics,
+                         opacities);
     while (todo) {
       const int t = __builtin_ctzll(todo);
       todo &= todo - 1;
