@@ -35,12 +35,17 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
     const int32_t *__restrict__ last_ids, const float *__restrict__ render_colors, int ed_channel,
     const float *__restrict__ v_render_colors, const float *__restrict__ v_render_alphas, int absgrad,
     float *__restrict__ v_geom, const GradSegs gs) {
+#ifdef PR_DIAG
+  const unsigned long long tk_start = __builtin_amdgcn_s_memtime();
+  unsigned long long dg_alpha = 0, dg_body = 0, dg_tail = 0, dg_iters = 0;
+#endif
   using Rg = Region<TS, PPL>;
   constexpr int ROW = color_row(CD);
   constexpr int CDP = round4(CD);
   constexpr int NQ = CDP / 4;                 // colour quads
   constexpr int NV = CDP + (GEOM ? 8 : 0);    // values reduced per Gaussian
-  __shared__ WaveLds<CD> lds[WPB];
+  constexpr int BS = batch_size(PPL);
+  __shared__ WaveLds<CD, true, BS> lds[WPB];
   const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // Without an explicit order, blocks that share an XCD take a contiguous range of tiles (neighbouring
   // tiles share Gaussians -> one L2).  With one, slot s processes tile tile_order[s]: the caller lists the
@@ -48,7 +53,7 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
   const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   const int region = (int)bid * WPB + wave;
   if (region >= n_regions) return;
-  WaveLds<CD> &L = lds[wave];
+  WaveLds<CD, true, BS> &L = lds[wave];
 
   const int tile_flat = tile_order ? tile_order[region / Rg::WPT] : region / Rg::WPT, sub = region % Rg::WPT;
   const int n_tiles = tile_w * tile_h;
@@ -153,19 +158,22 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
   const float rx0 = (float)(tx * TS) + 0.5f, ry0 = (float)(ty * TS + sub * Rg::RH) + 0.5f;
   const float rx1 = (float)min(tx * TS + TS, width) - 0.5f;
   const float ry1 = (float)min(ty * TS + sub * Rg::RH + Rg::RH, height) - 0.5f;
-  BatchGeometry pre = prefetch_batch(lane, max(range_lo, max_last - WAVE), max_last - max(range_lo, max_last - WAVE),
+  BatchGeometry pre = prefetch_batch(lane, max(range_lo, max_last - BS), max_last - max(range_lo, max_last - BS),
                                      flatten_ids, means2d, conics, opacities);
-  for (int bend = max_last; bend > range_lo; bend -= WAVE) {
-    const int first = max(range_lo, bend - WAVE);
-    unsigned long long todo = stage_batch<CD>(L, lane, pre, cs, N, D, ch_off, rx0, ry0, rx1, ry1);
+  for (int bend = max_last; bend > range_lo; bend -= BS) {
+    const int first = max(range_lo, bend - BS);
+    unsigned long long todo = stage_batch<CD, true, BS>(L, lane, pre, cs, N, D, ch_off, rx0, ry0, rx1, ry1);
     {  // the next batch's geometry travels while this one is composited
-      const int nend = bend - WAVE, nfirst = max(range_lo, nend - WAVE);
+      const int nend = bend - BS, nfirst = max(range_lo, nend - BS);
       pre = prefetch_batch(lane, nfirst, nend - nfirst, flatten_ids, means2d, conics, opacities);
     }
     while (todo) {
       const int t = 63 - __builtin_clzll(todo);
       todo &= ~(1ull << t);
       const int idx = first + t;
+#ifdef PR_DIAG
+      const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
       const float4 g = L.g4[t];
       const float2 h = L.g2[t];
       float dx[Rg::BW], dy[Rg::BH], adx2[Rg::BW], cdy2[Rg::BH], bdx[Rg::BW];
@@ -199,7 +207,8 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
       }
       if (any == 0ull) continue;
 #ifdef PR_DIAG
-      {
+      const unsigned long long tk1 = __builtin_amdgcn_s_memtime();
+      if (PR_DIAG == 1) {
         int npx = 0, nslots = 0;
         for (int j = 0; j < PPL; ++j) {
           npx += __builtin_popcountll(slot[j]);
@@ -286,6 +295,9 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
         composite(integral_constant<int, PPL / 2>{}, integral_constant<int, PPL>{});
       else
         composite(integral_constant<int, 0>{}, integral_constant<int, PPL>{});
+#ifdef PR_DIAG
+      const unsigned long long tk2 = __builtin_amdgcn_s_memtime();
+#endif
       // one lane per value: colours go to v_colors[gid, ch_off + k], the 8 geometry values to v_geom[gid, :]
 #pragma unroll
       for (int k0 = 0; k0 < NV; k0 += WAVE) {
@@ -310,8 +322,26 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
           }
         }
       }
+#ifdef PR_DIAG
+      {
+        const unsigned long long tk3 = __builtin_amdgcn_s_memtime();
+        dg_alpha += tk1 - tk0;   // record read + alpha + ballots
+        dg_body += tk2 - tk1;    // contractions, folds, geometry
+        dg_tail += tk3 - tk2;    // read-back + atomics
+        dg_iters += 1;
+      }
+#endif
     }
   }
+#ifdef PR_DIAG
+  if (lane == 0 && PR_DIAG == 2) {
+    atomicAdd(&g_diag[0], dg_iters);
+    atomicAdd(&g_diag[3], dg_alpha);
+    atomicAdd(&g_diag[4], dg_body);
+    atomicAdd(&g_diag[6], dg_tail);
+    atomicAdd(&g_diag[7], __builtin_amdgcn_s_memtime() - tk_start);   // whole wave
+  }
+#endif
 }
 
 template <int TS, int PPL, int CD, bool GEOM>

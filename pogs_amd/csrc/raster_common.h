@@ -69,15 +69,22 @@ constexpr int round4(int x) { return (x + 3) & ~3; }
 // lane's 16-byte store on the same banks.
 constexpr int color_row(int cd) { return round4(cd) % 32 == 0 ? round4(cd) + 4 : round4(cd); }
 
-template <int CD>
+// BWD adds the backward kernel's reduction area; the forward kernel leaves it out (LDS per wavefront decides
+// how many wavefronts a CU holds).
+// Intersections staged per batch.  A full wavefront's worth (one per lane) with 4 pixels per lane; half of
+// that with fewer pixels per lane, where the smaller LDS slice lets the CU hold the extra wavefronts the
+// smaller register footprint allows.
+constexpr int batch_size(int ppl) { return ppl >= 4 ? WAVE : WAVE / 2; }
+
+template <int CD, bool BWD, int BS>
 struct alignas(16) WaveLds {
-  float4 g4[WAVE];              // x, y, opacity, A' (= -0.5 a log2e)
-  float2 g2[WAVE];              // B' (= -b log2e), C' (= -0.5 c log2e)
-  int32_t ids[WAVE];            // flat Gaussian index
-  float col[WAVE * color_row(CD)];
+  float4 g4[BS];                // x, y, opacity, A' (= -0.5 a log2e)
+  float2 g2[BS];                // B' (= -b log2e), C' (= -0.5 c log2e)
+  int32_t ids[BS];              // flat Gaussian index
+  float col[BS * color_row(CD)];
   // backward: row-folded partial sums of the per-Gaussian values, [quad][lane] with a 68-float pitch so
   // that the 16-float row segments read back by consecutive lanes fall on distinct banks
-  float red[(round4(CD) / 4 + 2) * 68];
+  float red[BWD ? (round4(CD) / 4 + 2) * 68 : 4];
 };
 
 // The D composited channels of a Gaussian may live in up to three tensors laid side by side in channel order
@@ -167,9 +174,9 @@ __device__ __forceinline__ BatchGeometry prefetch_batch(int lane, int first, int
 
 // Stage a prefetched batch: lane j tests Gaussian j against the region and, if it can contribute, writes its
 // record and colour row to the wave's LDS slice.  Returns the wave-wide mask of staged Gaussians.
-template <int CD>
+template <int CD, bool BWD, int BS>
 __device__ __forceinline__ unsigned long long stage_batch(
-    WaveLds<CD> &L, int lane, const BatchGeometry &pre, const ColorSegs &cs, int N, int D, int ch_off, float rx0,
+    WaveLds<CD, BWD, BS> &L, int lane, const BatchGeometry &pre, const ColorSegs &cs, int N, int D, int ch_off, float rx0,
     float ry0, float rx1, float ry1) {
   constexpr int ROW = color_row(CD);
   bool keep = false;

@@ -15,7 +15,8 @@ __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
   using Rg = Region<TS, PPL>;
   constexpr int ROW = color_row(CD);
   constexpr int CDP = round4(CD);
-  __shared__ WaveLds<CD> lds[WPB];
+  constexpr int BS = batch_size(PPL);
+  __shared__ WaveLds<CD, false, BS> lds[WPB];
   const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // Without an explicit order, blocks that share an XCD take a contiguous range of tiles (neighbouring
   // tiles share Gaussians -> one L2).  With one, slot s processes tile tile_order[s]: the caller lists the
@@ -23,7 +24,7 @@ __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
   const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   const int region = (int)bid * WPB + wave;
   if (region >= n_regions) return;
-  WaveLds<CD> &L = lds[wave];
+  WaveLds<CD, false, BS> &L = lds[wave];
 
   const int tile_flat = tile_order ? tile_order[region / Rg::WPT] : region / Rg::WPT, sub = region % Rg::WPT;
   const int n_tiles = tile_w * tile_h;
@@ -56,12 +57,12 @@ __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
   const float rx1 = (float)min(tx * TS + TS, width) - 0.5f;
   const float ry1 = (float)min(ty * TS + sub * Rg::RH + Rg::RH, height) - 0.5f;
   bool all_done = false;
-  BatchGeometry pre = prefetch_batch(lane, range_lo, min(WAVE, range_hi - range_lo), flatten_ids, means2d, conics,
+  BatchGeometry pre = prefetch_batch(lane, range_lo, min(BS, range_hi - range_lo), flatten_ids, means2d, conics,
                                      opacities);
-  for (int first = range_lo; first < range_hi && !all_done; first += WAVE) {
-    unsigned long long todo = stage_batch<CD>(L, lane, pre, cs, N, D, ch_off, rx0, ry0, rx1, ry1);
+  for (int first = range_lo; first < range_hi && !all_done; first += BS) {
+    unsigned long long todo = stage_batch<CD, false, BS>(L, lane, pre, cs, N, D, ch_off, rx0, ry0, rx1, ry1);
     // the next batch's geometry travels while this one is composited
-    pre = prefetch_batch(lane, first + WAVE, min(WAVE, range_hi - first - WAVE), flatten_ids, means2d, conics,
+    pre = prefetch_batch(lane, first + BS, min(BS, range_hi - first - BS), flatten_ids, means2d, conics,
                          opacities);
     while (todo) {
       const int t = __builtin_ctzll(todo);
@@ -208,7 +209,11 @@ static FwdPlan plan_fwd(int D, int tile_size, int64_t n_tiles_total) {
     return p;
   }
   const int cd = pick_chunk(p.per);
-  p.ppl = cd <= 48 ? 4 : cd <= 72 ? 2 : 1;
+  // Narrow chunks: 4 pixels per lane (few registers either way).  From 25 channels on, 2 pixels per lane: half
+  // the accumulators -> <= 128 registers -> three to four wavefronts per SIMD instead of two, which matters
+  // more than the per-Gaussian work a second wavefront per tile repeats (a wavefront issues at most one
+  // vector instruction every four cycles, the SIMD takes one every two): 0.52 vs 0.57 ms at 36 channels.
+  p.ppl = cd <= 24 ? 4 : cd <= 72 ? 2 : 1;
   while (p.ppl > 1 && n_tiles_total * (4 / p.ppl) < 3072) p.ppl >>= 1;
   const int forced = env_int("POGS_RAST_FWD_PPL", 0);
   if (forced == 1 || (forced == 2 && cd <= 72) || (forced == 4 && cd <= 48)) p.ppl = forced;

@@ -22,7 +22,9 @@ def step():
     return meta
 step(); torch.cuda.synchronize(); lib.pr_diag_read(out, 1)
 meta = step(); torch.cuda.synchronize(); lib.pr_diag_read(out, 1)
-it, npx, nslots, nrows, nhalf, nlanes = [int(x) for x in out[:6]]
+it, npx, nslots, c_alpha, c_body, nlanes, c_tail, c_wave = [int(x) for x in out[:8]]
 print(json.dumps({"cfg": sys.argv[1:], "I": meta["n_composited_isects"], "contributing_iters": it, "active_px_per_iter": npx / it,
-                  "active_slots_per_iter": nslots / it, "active_rows_per_iter": nrows / it, "active_halves_per_iter": nhalf / it,
-                  "active_lanes_per_iter": nlanes / it}))
+                  "active_slots_per_iter": nslots / it, "active_lanes_per_iter": nlanes / it,
+                  "cycles_per_contributing_iter": {"record+alpha": c_alpha / it, "contractions+geometry": c_body / it,
+                                                   "readback+atomics": c_tail / it},
+                  "wave_cycles_total_per_iter": c_wave / it}))
