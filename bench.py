@@ -241,6 +241,20 @@ def main():
                     traffic = rec.get(dom)
             except Exception:
                 traffic = None
+        # measured HBM peak beside the nominal one: a 1 GiB device-to-device copy (read + write)
+        a_buf = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        b_buf = torch.empty_like(a_buf)
+        for _ in range(2):
+            b_buf.copy_(a_buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b_buf.copy_(a_buf)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * a_buf.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a_buf, b_buf
         out = {
             "metric": "Mpix/s fwd+bwd (1M Gauss, 1080p, RGB+32ch feat)", "value": value, "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -255,7 +269,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "measured_copy_peak_GBps": copy_gbs,
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms,
                 "whole_call": {"algorithmic_bytes": total_bytes, "achieved": total_bytes / (ms_per_step * 1e-3) / 1e9,
                                "frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
