@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
   constexpr int CDP = round4(CD);
   constexpr int NQ = CDP / 4;                 // colour quads
   constexpr int NV = CDP + (GEOM ? 8 : 0);    // values reduced per Gaussian
-  constexpr int BS = batch_size(PPL);
+  // 1 pixel per lane: 16-entry batches keep the slice (colours + reduction area) under 10 KB = 4 wavefronts/SIMD
+  constexpr int BS = PPL == 1 ? 16 : batch_size(PPL);
   __shared__ WaveLds<CD, true, BS> lds[WPB];
   const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
   // Without an explicit order, blocks that share an XCD take a contiguous range of tiles (neighbouring

@@ -200,6 +200,7 @@ def _pinned_count(dev: torch.device) -> Tensor:
 
 
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
+_ASYNC_DEPTH_ORDER_MIN = 100_000
 
 
 def _depth_order_async(depths: Tensor):
@@ -609,7 +610,8 @@ def rasterization(
     radii, means2d, depths, conics, compensations = fully_fused_projection(
         means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
         calc_compensations=(rasterize_mode == "antialiased"))
-    depth_order = _depth_order_async(depths) if C * N > 0 else None
+    # small models: the second stream's hand-offs cost more than the overlap gains
+    depth_order = _depth_order_async(depths) if C * N >= _ASYNC_DEPTH_ORDER_MIN else None
     opac = opacities[None, :].expand(C, N)
     if compensations is not None:
         opac = opac * compensations
