@@ -207,6 +207,22 @@ typedef struct {
 int pr_adam_max_groups(void);
 int pr_adam_step(const pr_adam_group *groups, int n_groups, void *stream);
 
+/* ---- fused channel MLP on the rendered feature image ------------------------------------------------------
+ * Replaces pogs/pogs.py:516-522 with the module of pogs/pogs.py:153-161: for every pixel
+ *   x = alpha > 0 ? feats / max(alpha, 1e-6) : 0            (skipped when alphas is NULL)
+ *   y = W3 relu(W2 relu(W1 relu(W0 x)))                      (Wl: [64 out, 64 in] row-major, torch.nn.Linear.weight)
+ *   y = 0 where alpha < zero_below                           (the reference's eval-mode cut at 0.8; <= 0: none)
+ * in exact float32 on the matrix cores.  feats/out: [n_pixels, 64], 16-byte aligned; alphas: [n_pixels].
+ * masks (may be NULL in pr_mlp_fwd): pr_mlp_mask_words(n_pixels) 64-bit words that receive the ReLU signs the
+ * backward needs.  pr_mlp_bwd_input: gradient with respect to feats for FROZEN weights (what the tracker
+ * needs; alpha receives no gradient, as in the reference where it is detached). */
+size_t pr_mlp_mask_words(int64_t n_pixels);
+int pr_mlp_fwd(int64_t n_pixels, const float *feats, const float *alphas, const float *w0, const float *w1,
+               const float *w2, const float *w3, float zero_below, float *out, uint64_t *masks, void *stream);
+int pr_mlp_bwd_input(int64_t n_pixels, const float *v_out, const float *alphas, const float *w0, const float *w1,
+                     const float *w2, const float *w3, float zero_below, const uint64_t *masks, float *v_feats,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

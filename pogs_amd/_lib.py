@@ -39,6 +39,9 @@ SIGNATURES = {
                               c_int64, c_int, _P, _P, _P, _P, c_int, _P]),
     "pr_raster_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                               c_int64, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "pr_mlp_mask_words": (c_size_t, [c_int64]),
+    "pr_mlp_fwd": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "pr_mlp_bwd_input": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "pr_adam_max_groups": (c_int, []),
     "pr_adam_step": (c_int, [_P, c_int, _P]),
     "pr_rigid_fwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -51,7 +51,7 @@ def _worker(rank, world, port, n_views, ret):
     assert all(torch.equal(gathered[0], t) for t in gathered)
     assert p["means"].grad.data_ptr() == grads.flat.data_ptr() + grads.offsets[0] * 8
     if rank == 0:
-        ret.put({k: v.grad.clone() for k, v in p.items()})
+        ret.put({k: v.grad.numpy().copy() for k, v in p.items()})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -73,7 +73,8 @@ def _exchange_worker(rank, world, port, ret):
     params["small_a"].grad = params["small_a"].grad.t().contiguous().t()   # a non-contiguous gradient
     ex.all_reduce_mean()
     if rank == 0:
-        ret.put({k: p.grad.clone() for k, p in params.items()})
+        ret.put({k: p.grad.numpy().copy() for k, p in params.items()})   # plain arrays: no shared-memory handles
+        #                                                             that die with this process
     dist.barrier()
     dist.destroy_process_group()
 
@@ -94,7 +95,7 @@ def test_in_place_gradient_exchange_averages_over_ranks():
     base = {k: torch.randn(s, generator=g, dtype=torch.float64) for k, s in shapes.items()}
     for k, v in got.items():
         want = base[k] * (0.5 if k == "unused" else 1.5)            # mean of 1x and 2x (or of 1x and nothing)
-        assert torch.allclose(v, want, atol=1e-12), k
+        assert torch.allclose(torch.from_numpy(v), want, atol=1e-12), k
 
 
 @pytest.mark.parametrize("n_views", [2, 3])
@@ -115,7 +116,7 @@ def test_sharded_step_matches_single_process_mean(n_views):
         _render_view(sc, p, v)
     for k in p:
         ref = p[k].grad / n_views
-        assert torch.allclose(got[k], ref, rtol=1e-10, atol=1e-12), k
+        assert torch.allclose(torch.from_numpy(got[k]), ref, rtol=1e-10, atol=1e-12), k
 
 
 def test_view_assignment_covers_every_view_once():
