@@ -223,6 +223,58 @@ int pr_mlp_bwd_input(int64_t n_pixels, const float *v_out, const float *alphas, 
                      const float *w2, const float *w3, float zero_below, const uint64_t *masks, float *v_feats,
                      void *stream);
 
+/* ---- densification: grow / prune the Gaussian set after the backward pass ---------------------------------
+ * Replaces gsplat 1.4.0's DefaultStrategy (third-party gsplat/strategy/default.py, ops.py) as constructed at
+ * nerfstudio/models/splatfacto.py:264-281 and driven at pogs/pogs.py:373-379 (step_pre_backward) and
+ * nerfstudio/models/splatfacto.py:365-375 (step_post_backward). */
+
+/* Per training step (DefaultStrategy._update_state, unpacked): for every Gaussian i and every camera c with
+ * radii[c,i] > 0:  grad2d[i] += |(gx * width/2 * n_cameras, gy * height/2 * n_cameras)|,  count[i] += 1,
+ * radii_max[i] = max(radii_max[i], radii[c,i] / max(width, height)) (radii_max may be NULL).
+ * grads2d: [C,N,2] float (means2d.grad or .absgrad), radii: [C,N] int32. */
+int pr_densify_accumulate(int C, int N, const float *grads2d, const int32_t *radii, int width, int height,
+                          int n_cameras, float *grad2d, float *count, float *radii_max, void *stream);
+
+/* Thresholds of one refinement, already multiplied by the scene scale where the strategy does so. */
+typedef struct pr_densify_rule {
+  float grow_grad2d;    /* duplicate/split when grad2d/max(count,1) exceeds it */
+  float grow_scale3d;   /* ... duplicate when max(exp(scales)) <= it, else split */
+  float grow_scale2d;   /* also split when radii_max exceeds it (only if grow_by_radius) */
+  float prune_opa;      /* prune when sigmoid(opacity) is below it */
+  float prune_scale3d;  /* prune when max(exp(scales)) exceeds it (only if prune_big) */
+  float prune_scale2d;  /* ... or radii_max exceeds it (only if prune_by_radius) */
+  int grow_by_radius;   /* step < refine_scale2d_stop_iter */
+  int prune_big;        /* step > reset_every */
+  int prune_by_radius;  /* prune_big and step < refine_scale2d_stop_iter */
+  int revised_opacity;  /* children get opacity 1 - sqrt(1 - o) */
+} pr_densify_rule;
+
+/* Refinement, step 1 (DefaultStrategy._grow_gs + _prune_gs decisions): classify all N Gaussians and scan.
+ * counts_dev[4] (device) = {n_out, n_duplicated, n_split, n_pruned}; scratch (256-byte aligned,
+ * pr_densify_plan_scratch_bytes(N)) carries the plan to pr_densify_emit.  scales [N,3] and opacities [N] are
+ * the raw (log / logit) parameters. */
+size_t pr_densify_plan_scratch_bytes(int N);
+int pr_densify_plan(int N, const float *grad2d, const float *count, const float *scales, const float *opacities,
+                    const float *radii_max, const pr_densify_rule *rule, int32_t *counts_dev, void *scratch,
+                    size_t scratch_bytes, void *stream);
+/* Step 2: the gather map of the new set, n_out = counts_dev[0] entries, in the order duplicate -> split ->
+ * remove (ops.py) leave: kept originals that were not split, kept copies, kept first children, kept second
+ * children.  map_src[m] = source Gaussian; map_tag[m] = kind << 30 | r, kind 0 original, 1 copy, 2/3 first /
+ * second child, r = rank of the source among all split sources (row of the noise samples). */
+int pr_densify_emit(int N, const void *scratch, size_t scratch_bytes, int64_t n_out, int32_t *map_src,
+                    int32_t *map_tag, void *stream);
+/* Step 3: dst[m,:] = src[map_src[m],:] for rows of `width` floats; zero_new != 0 writes zeros for every entry
+ * that is not an original (optimiser moments of new Gaussians, ops.py duplicate/split optimizer_fn). */
+int pr_densify_gather(int64_t n_out, int width, const float *src, const int32_t *map_src, const int32_t *map_tag,
+                      int zero_new, float *dst, void *stream);
+/* Step 4 (ops.py split): overwrite the children's rows: means_out = mean + R(q/|q|) (exp(scale) * noise[b,r,:]),
+ * scales_out = log(exp(scale) / 1.6), and, when opacities_out is not NULL, the revised opacity.
+ * noise: [2, n_split, 3] standard-normal samples. */
+int pr_densify_split_children(int64_t n_out, const int32_t *map_src, const int32_t *map_tag, int64_t n_split,
+                              const float *means, const float *scales, const float *quats, const float *opacities,
+                              const float *noise, float *means_out, float *scales_out, float *opacities_out,
+                              void *stream);
+
 #ifdef __cplusplus
 }
 #endif

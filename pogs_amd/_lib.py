@@ -42,6 +42,12 @@ SIGNATURES = {
     "pr_mlp_mask_words": (c_size_t, [c_int64]),
     "pr_mlp_fwd": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "pr_mlp_bwd_input": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "pr_densify_accumulate": (c_int, [c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "pr_densify_plan_scratch_bytes": (c_size_t, [c_int]),
+    "pr_densify_plan": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "pr_densify_emit": (c_int, [c_int, _P, c_size_t, c_int64, _P, _P, _P]),
+    "pr_densify_gather": (c_int, [c_int64, c_int, _P, _P, _P, c_int, _P, _P]),
+    "pr_densify_split_children": (c_int, [c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pr_adam_max_groups": (c_int, []),
     "pr_adam_step": (c_int, [_P, c_int, _P]),
     "pr_rigid_fwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -61,6 +67,14 @@ class AdamGroup(ctypes.Structure):
     _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
                 ("exp_avg_sq", ctypes.c_void_p), ("numel", c_int64), ("step", c_int64), ("lr", ctypes.c_double),
                 ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_double)]
+
+
+class DensifyRule(ctypes.Structure):
+    """pr_densify_rule."""
+    _fields_ = [("grow_grad2d", c_float), ("grow_scale3d", c_float), ("grow_scale2d", c_float),
+                ("prune_opa", c_float), ("prune_scale3d", c_float), ("prune_scale2d", c_float),
+                ("grow_by_radius", c_int), ("prune_big", c_int), ("prune_by_radius", c_int),
+                ("revised_opacity", c_int)]
 
 
 def segment_array(items):
