@@ -159,6 +159,280 @@ __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
   }
 }
 
+// ---- matrix-core variant (16x16 tiles, 2 pixels per lane, 25..48 channels per pass) ------------------------
+// The colour accumulation out[p][c] += vis[p][g] * colour[g][c] of 16 Gaussians at a time is one matrix
+// product per 32-pixel group, out^T (32 channels x 32 pixels) += C^T (32 x 16) . V^T (16 x 32), on
+// v_mfma_f32_32x32x16_bf16 with both operands split into a bf16 head and a bf16 residual
+// (hi.hi + lo.hi + hi.lo: 16 mantissa bits, error <= 2^-16 per product, well inside the 1e-4 image tolerance).
+// The weights need no data movement: a lane computes vis for ITS pixel and 16 Gaussians in a row, which is
+// the B operand's register index; since lanes l and l+32 are different pixels here but the same matrix column
+// in the operand layout (rows 8h .. 8h+7 on lane half h), one v_permlane32_swap per register pair turns
+// "slots 0-7 / slots 8-15 of my pixel" into "operand of pixels 0-31 / operand of pixels 32-63".  The result has
+// the pixel on the lane and the channels in the accumulator registers for the whole tile.  Channels past the
+// first 32 of the pass (the expected-depth channel among them in the usual [rgb | features | depth] order)
+// stay on the vector ALU in float32.
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+// (a, b) -> packed bf16 heads and packed bf16 residuals
+__device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo) {
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2v));
+  const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a - ha, b - hb}, bf2v));
+}
+__device__ __forceinline__ void swap32(unsigned a, unsigned b, unsigned &lo_tile, unsigned &hi_tile) {
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  lo_tile = r[0];
+  hi_tile = r[1];
+  asm("" : "+v"(lo_tile), "+v"(hi_tile));
+}
+__device__ __forceinline__ f16v mfma_bf16(const unsigned (&a)[4], const unsigned (&b)[4], f16v c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, u4v{a[0], a[1], a[2], a[3]}),
+                                                 __builtin_bit_cast(bf8v, u4v{b[0], b[1], b[2], b[3]}), c, 0, 0, 0);
+}
+
+template <int CD>
+__global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
+    int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
+    const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
+    int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
+    const int32_t *__restrict__ tile_order, const int32_t *__restrict__ flatten_ids, int n_isects, int ed_channel,
+    float *__restrict__ render_colors, float *__restrict__ render_alphas, int32_t *__restrict__ last_ids) {
+  constexpr int PPL = 2, GS = 16;        // pixels per lane; Gaussians per matrix product
+  using Rg = Region<16, PPL>;
+  constexpr int ROW = color_row(CD), CDP = round4(CD), BS = batch_size(PPL);
+  constexpr int CM = 32;                 // channels on the matrix cores
+  constexpr int CV = CDP - CM, CV2 = CV / 2;  // channels on the vector ALU
+  static_assert(CD >= CM && CV >= 0 && CV <= 16, "pass width");
+  __shared__ WaveLds<CD, false, BS> L;
+  const int lane = threadIdx.x & 63;
+  const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  const int region = (int)bid;
+  if (region >= n_regions) return;
+
+  const int tile_flat = tile_order ? tile_order[region / Rg::WPT] : region / Rg::WPT, sub = region % Rg::WPT;
+  const int n_tiles = tile_w * tile_h;
+  const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
+  const int ty = tile / tile_w, tx = tile % tile_w;
+  const int x0 = tx * 16 + (lane % Rg::LX) * Rg::PX;
+  const int y0 = ty * 16 + sub * Rg::RH + (lane / Rg::LX) * Rg::PY;
+  const int range_lo = isect_offsets[tile_flat];
+  const int range_hi = (tile_flat + 1 < n_regions / Rg::WPT) ? isect_offsets[tile_flat + 1] : n_isects;
+
+  // T: transmittance the pixel has reached (what alpha and the background see); Tl: the same while the pixel
+  // still accepts Gaussians, 0 once it is saturated or if it lies outside the image -- every test on "is this
+  // pixel finished" is then arithmetic on Tl (a weight alpha * Tl of 0) instead of a flag carried per pixel.
+  float T[PPL], Tl[PPL];
+  f16v acc[PPL][2];                      // [pixel slot][lane half of the pixel]: 32 channels x 32 pixels each
+  f2 accv[PPL][CV2 > 0 ? CV2 : 1];
+  int last[PPL];
+  bool inside[PPL];
+  const float px0 = (float)x0 + 0.5f, py0 = (float)y0 + 0.5f;
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    const int x = x0, y = y0 + j * Rg::SY;
+    inside[j] = x < width && y < height;
+    T[j] = 1.f;
+    Tl[j] = inside[j] ? 1.f : 0.f;
+    last[j] = range_lo;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][hh][r] = 0.f;
+#pragma unroll
+    for (int k = 0; k < (CV2 > 0 ? CV2 : 1); ++k) accv[j][k] = splat(0.f);
+  }
+
+  const float rx0 = (float)(tx * 16) + 0.5f, ry0 = (float)(ty * 16 + sub * Rg::RH) + 0.5f;
+  const float rx1 = (float)min(tx * 16 + 16, width) - 0.5f;
+  const float ry1 = (float)min(ty * 16 + sub * Rg::RH + Rg::RH, height) - 0.5f;
+  const int mc = lane & 31, mh = lane >> 5;   // this lane's row (channel) and k half in the A operand
+  bool all_done = false;
+  BatchGeometry pre = prefetch_batch(lane, range_lo, min(BS, range_hi - range_lo), flatten_ids, means2d, conics,
+                                     opacities);
+  for (int first = range_lo; first < range_hi && !all_done; first += BS) {
+    unsigned long long todo = stage_batch<CD, false, BS>(L, lane, pre, cs, N, D, ch_off, rx0, ry0, rx1, ry1);
+    pre = prefetch_batch(lane, first + BS, min(BS, range_hi - first - BS), flatten_ids, means2d, conics, opacities);
+    while (todo) {
+      unsigned wh[PPL][GS / 2], wl[PPL][GS / 2];  // packed weights: [slot][i] = Gaussians 2i, 2i+1 of the group
+      float ca[GS / 2];                           // A operand, this lane's k half: colour mc of members 8 mh + i
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < GS / 2; ++i) ca[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < GS; s += 2) {
+        float w[PPL][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int j = 0; j < PPL; ++j) w[j][u] = 0.f;
+          int t = -1;
+          if (todo) {
+            t = __builtin_ctzll(todo);
+            todo &= todo - 1;
+          }
+          if (t < 0) continue;
+          {  // lanes of half mh carry members 8 mh .. 8 mh + 7 of the group in the A operand
+            const float c = L.col[t * ROW + mc];
+            ca[(s + u) & 7] = (mh == ((s + u) >> 3)) ? c : ca[(s + u) & 7];
+          }
+          const float4 g = L.g4[t];
+          const float2 h = L.g2[t];
+          const float dx = g.x - px0, adx2 = g.w * dx * dx, bdx = h.x * dx;
+#pragma unroll
+          for (int j = 0; j < PPL; ++j) {
+            const float dy = g.y - (py0 + (float)(j * Rg::SY));
+            const float power = adx2 + h.y * dy * dy + bdx * dy;  // = -sigma * log2(e)
+            const float alpha = fminf(ALPHA_MAX, g.z * __builtin_amdgcn_exp2f(power));
+            const bool valid = (power <= 0.f) && (alpha >= ALPHA_MIN);
+            const float next_T = Tl[j] - alpha * Tl[j];
+            const bool contrib = valid && (next_T > T_STOP);   // never for a finished pixel: next_T = 0
+            w[j][u] = contrib ? alpha * Tl[j] : 0.f;
+            Tl[j] = valid ? (contrib ? next_T : 0.f) : Tl[j];  // valid but not composited = the pixel saturates here
+            T[j] = contrib ? next_T : T[j];
+            last[j] = contrib ? first + t + 1 : last[j];
+            any = any || contrib;
+          }
+          if (CV > 0) {
+            const float4 *crow = reinterpret_cast<const float4 *>(L.col + t * ROW + CM);
+#pragma unroll
+            for (int q = 0; q < CV / 4; ++q) {
+              const float4 c = crow[q];
+              const f2 c01 = {c.x, c.y}, c23 = {c.z, c.w};
+#pragma unroll
+              for (int j = 0; j < PPL; ++j) {
+                const f2 v = splat(w[j][u]);
+                accv[j][2 * q] = fma2(c01, v, accv[j][2 * q]);
+                accv[j][2 * q + 1] = fma2(c23, v, accv[j][2 * q + 1]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+          split_pair(w[j][0], w[j][1], wh[j][s / 2], wl[j][s / 2]);
+          // convert here, not lazily at the matrix product: the float weights die and 16 registers are saved
+          asm volatile("" : "+v"(wh[j][s / 2]), "+v"(wl[j][s / 2]));
+        }
+        // every pixel of the region is saturated: the rest of the group (and of the list) is not needed
+        if ((s & 3) == 2) {
+          bool live = false;
+#pragma unroll
+          for (int j = 0; j < PPL; ++j) live = live || Tl[j] > 0.f;
+          if (__builtin_amdgcn_ballot_w64(live) == 0ull) {
+            todo = 0ull;
+            all_done = true;
+          }
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
+        // A operand: row = channel mc, k = group members 8 mh .. 8 mh + 7
+        unsigned ah[4], al[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split_pair(ca[2 * i], ca[2 * i + 1], ah[i], al[i]);
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+          unsigned b0h[4], b1h[4], b0l[4], b1l[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            swap32(wh[j][i], wh[j][4 + i], b0h[i], b1h[i]);
+            swap32(wl[j][i], wl[j][4 + i], b0l[i], b1l[i]);
+          }
+          acc[j][0] = mfma_bf16(ah, b0h, acc[j][0]);
+          acc[j][1] = mfma_bf16(ah, b1h, acc[j][1]);
+          acc[j][0] = mfma_bf16(al, b0h, acc[j][0]);
+          acc[j][1] = mfma_bf16(al, b1h, acc[j][1]);
+          acc[j][0] = mfma_bf16(ah, b0l, acc[j][0]);
+          acc[j][1] = mfma_bf16(ah, b1l, acc[j][1]);
+        }
+      }
+      if (all_done) break;
+    }
+  }
+
+  const int nch = min(CD, D - ch_off);
+  const bool aligned = ((D | ch_off) & 3) == 0;
+  // matrix part: accumulator [j][hh] of this lane belongs to the pixel of lane pl = 32 hh + (lane & 31)
+#pragma unroll
+  for (int j = 0; j < PPL; ++j)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int pl = 32 * hh + mc;
+      const float Tp = __shfl(T[j], pl);
+      const int x = tx * 16 + (pl % Rg::LX), y = ty * 16 + sub * Rg::RH + pl / Rg::LX + j * Rg::SY;
+      if (x >= width || y >= height) continue;
+      const int64_t pix = ((int64_t)cam * height + y) * width + x;
+      float *out = render_colors + pix * D + ch_off;
+      const float inv = 1.f / fmaxf(1.f - Tp, 1e-10f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = 8 * q + 4 * mh;  // channels c0 .. c0+3 of the pass sit in registers 4q .. 4q+3
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[j][hh][4 * q + i];
+          if (backgrounds && c0 + i < nch) v[i] = fmaf(Tp, backgrounds[(int64_t)cam * D + ch_off + c0 + i], v[i]);
+          if (c0 + i + ch_off == ed_channel) v[i] *= inv;
+        }
+        if (aligned) {
+          if (c0 < nch) *reinterpret_cast<float4 *>(out + c0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (c0 + i < nch) out[c0 + i] = v[i];
+        }
+      }
+    }
+  // vector part and the per-pixel scalars: the pixel's own lane
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    if (!inside[j]) continue;
+    const int x = x0, y = y0 + j * Rg::SY;
+    const int64_t pix = ((int64_t)cam * height + y) * width + x;
+    float *out = render_colors + pix * D + ch_off;
+    if (CV > 0) {
+      const float inv = 1.f / fmaxf(1.f - T[j], 1e-10f);
+#pragma unroll
+      for (int k = 0; k < CV; ++k) {
+        float v = accv[j][k / 2][k % 2];
+        if (backgrounds && CM + k < nch) v = fmaf(T[j], backgrounds[(int64_t)cam * D + ch_off + CM + k], v);
+        if (CM + k + ch_off == ed_channel) v *= inv;
+        accv[j][k / 2][k % 2] = v;
+      }
+      if (aligned) {
+#pragma unroll
+        for (int k = 0; k < CV; k += 4)
+          if (CM + k < nch)
+            *reinterpret_cast<float4 *>(out + CM + k) =
+                make_float4(accv[j][k / 2][0], accv[j][k / 2][1], accv[j][k / 2 + 1][0], accv[j][k / 2 + 1][1]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < CV; ++k)
+          if (CM + k < nch) out[CM + k] = accv[j][k / 2][k % 2];
+      }
+    }
+    if (ch_off == 0) {
+      render_alphas[pix] = 1.f - T[j];
+      last_ids[pix] = last[j];
+    }
+  }
+}
+
+template <int CD>
+static int launch_fwd_mfma(int C, int N, int D, int ch_off, const float *means2d, const float *conics,
+                           const ColorSegs &cs, const float *opacities, const float *backgrounds, int width, int height,
+                           int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
+                           const int32_t *flatten_ids, int64_t n_isects, int ed_channel, float *render_colors,
+                           float *render_alphas, int32_t *last_ids, hipStream_t stream) {
+  const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<16, 2>::WPT;
+  hipLaunchKernelGGL((raster_fwd_mfma_kernel<CD>), dim3((unsigned)n_regions), dim3(64), 0, stream, (int)n_regions, N, D,
+                     ch_off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
+                     tile_order, flatten_ids, (int)n_isects, ed_channel, render_colors, render_alphas, last_ids);
+  return check_launch("raster_fwd_mfma_kernel");
+}
+
 template <int TS, int PPL, int CD>
 static int launch_fwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const ColorSegs &cs,
                       const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
@@ -252,6 +526,7 @@ extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const fl
   int rcs = make_color_segs(colors, D, segments, n_segments, n_isects > 0, cs);
   if (rcs) return rcs;
   const FwdPlan plan = plan_fwd(D, tile_size, (int64_t)C * tile_w * tile_h);
+  const bool use_mfma = env_int("POGS_RAST_FWD_MFMA", 1) != 0;  // 0: vector-ALU kernels only (for A/B runs)
   for (int off = 0; off < D; off += plan.per) {
     const int cd = pick_chunk(min(plan.per, D - off));
     int rc = PR_EUNSUPPORTED;
@@ -264,6 +539,12 @@ extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const fl
       switch (cd) {
         FWD_CASE(16, 4, 4) FWD_CASE(16, 4, 8) FWD_CASE(16, 4, 16) FWD_CASE(16, 4, 24) FWD_CASE(16, 4, 32)
         FWD_CASE(16, 4, 36) FWD_CASE(16, 4, 48)
+      }
+    } else if (plan.ppl == 2 && use_mfma && (cd == 32 || cd == 36 || cd == 48)) {
+      switch (cd) {
+        case 32: rc = launch_fwd_mfma<32>(FWD_ARGS); break;
+        case 36: rc = launch_fwd_mfma<36>(FWD_ARGS); break;
+        case 48: rc = launch_fwd_mfma<48>(FWD_ARGS); break;
       }
     } else if (plan.ppl == 2) {
       switch (cd) {
