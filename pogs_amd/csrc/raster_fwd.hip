@@ -36,17 +36,20 @@ __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
   const int range_hi = (tile_flat + 1 < n_regions / Rg::WPT) ? isect_offsets[tile_flat + 1] : n_isects;
 
   constexpr int CH2 = CDP / 2;  // channel pairs
-  float T[PPL];
+  // T: transmittance the pixel has reached; Tl: the same while the pixel still accepts Gaussians, 0 once it is
+  // saturated or if it lies outside the image -- "is this pixel finished" is then arithmetic (a weight of
+  // alpha * Tl = 0) rather than a flag carried per pixel through the loop.
+  float T[PPL], Tl[PPL];
   f2 acc[PPL][CH2];
   int last[PPL];
-  bool done[PPL], inside[PPL];
+  bool inside[PPL];
   const float px0 = (float)x0 + 0.5f, py0 = (float)y0 + 0.5f;
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
     int x = x0 + (j % Rg::BW) * Rg::SX, y = y0 + (j / Rg::BW) * Rg::SY;
     inside[j] = x < width && y < height;
-    done[j] = !inside[j];
     T[j] = 1.f;
+    Tl[j] = inside[j] ? 1.f : 0.f;
     last[j] = range_lo;
 #pragma unroll
     for (int k = 0; k < CH2; ++k) acc[j][k] = splat(0.f);
@@ -84,22 +87,21 @@ __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
         dy[i] = g.y - (py0 + (float)(i * Rg::SY));
         cdy2[i] = h.y * dy[i] * dy[i];
       }
-      bool all = true;
+      bool live = false;
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
         const int jx = j % Rg::BW, jy = j / Rg::BW;
         const float power = adx2[jx] + cdy2[jy] + bdx[jx] * dy[jy];  // = -sigma * log2(e)
         const float alpha = fminf(ALPHA_MAX, g.z * __builtin_amdgcn_exp2f(power));
-        const bool valid = (power <= 0.f) && (alpha >= ALPHA_MIN) && !done[j];
-        const float next_T = T[j] - alpha * T[j];
-        const bool stop = valid && (next_T <= T_STOP);
-        const bool contrib = valid && !stop;
-        done[j] = done[j] || stop;
-        vis[j] = contrib ? alpha * T[j] : 0.f;
+        const bool valid = (power <= 0.f) && (alpha >= ALPHA_MIN);
+        const float next_T = Tl[j] - alpha * Tl[j];
+        const bool contrib = valid && (next_T > T_STOP);   // never for a finished pixel: next_T = 0
+        vis[j] = contrib ? alpha * Tl[j] : 0.f;
+        Tl[j] = valid ? (contrib ? next_T : 0.f) : Tl[j];  // valid but not composited: the pixel saturates here
         T[j] = contrib ? next_T : T[j];
         last[j] = contrib ? first + t + 1 : last[j];
         any = any || contrib;
-        all = all && done[j];
+        live = live || Tl[j] > 0.f;
       }
       if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
         const float4 *crow = reinterpret_cast<const float4 *>(L.col + t * ROW);
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
           }
         }
       }
-      if (__builtin_amdgcn_ballot_w64(!all) == 0ull) {
+      if (__builtin_amdgcn_ballot_w64(live) == 0ull) {
         all_done = true;
         break;
       }
