@@ -26,7 +26,10 @@ namespace pr {
 __device__ unsigned long long g_diag[8];
 #endif
 
-template <int TS, int PPL, int CD, bool GEOM>
+// GEOM: gradients of the 2D means, conics and opacities are wanted (needs the dot product S);  CGRAD: gradients of
+// the colours are wanted.  A caller that optimises poses through frozen appearance (the tracker) asks for GEOM only:
+// the per-channel accumulation, its folds and its read-back -- most of the per-Gaussian work -- are compiled out.
+template <int TS, int PPL, int CD, bool GEOM, bool CGRAD>
 __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
     const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
@@ -43,7 +46,10 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
   constexpr int ROW = color_row(CD);
   constexpr int CDP = round4(CD);
   constexpr int NQ = CDP / 4;                 // colour quads
-  constexpr int NV = CDP + (GEOM ? 8 : 0);    // values reduced per Gaussian
+  constexpr int CDR = CGRAD ? CDP : 0;        // colour values reduced per Gaussian
+  constexpr int NQR = CDR / 4;                // ... as quads in the reduction area
+  constexpr int NV = CDR + (GEOM ? 8 : 0);    // values reduced per Gaussian
+  static_assert(GEOM || CGRAD, "nothing to compute");
   // 1 pixel per lane: 16-entry batches keep the slice (colours + reduction area) under 10 KB = 4 wavefronts/SIMD
   constexpr int BS = PPL == 1 ? 16 : batch_size(PPL);
   __shared__ WaveLds<CD, true, BS> lds[WPB];
@@ -135,7 +141,7 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
   // post-scale of the geometry totals: x y (-ln2), conic a c (1/2), b, opacity (1), |x| |y| (ln2)
   float gscale = 1.f;
   if (GEOM) {
-    const int gi = lane - CDP;
+    const int gi = lane - CDR;
     gscale = (gi == 0 || gi == 1) ? -LN2 : (gi == 2 || gi == 4) ? 0.5f : (gi == 6 || gi == 7) ? LN2 : 1.f;
   }
 
@@ -252,11 +258,13 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
               S2[j] = fma2(c01, vout[j][2 * q], S2[j]);
               S2[j] = fma2(c23, vout[j][2 * q + 1], S2[j]);
             }
-            const f2 f = splat(fac[j]);
-            a01 = fma2(f, vout[j][2 * q], a01);
-            a23 = fma2(f, vout[j][2 * q + 1], a23);
+            if (CGRAD) {
+              const f2 f = splat(fac[j]);
+              a01 = fma2(f, vout[j][2 * q], a01);
+              a23 = fma2(f, vout[j][2 * q + 1], a23);
+            }
           }
-          red[q * 68 + lane] = quad_fold_rows(a01[0], a01[1], a23[0], a23[1]);
+          if (CGRAD) red[q * 68 + lane] = quad_fold_rows(a01[0], a01[1], a23[0], a23[1]);
         }
         if (GEOM) {
           float geo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // x y a b c o |x| |y|
@@ -282,8 +290,8 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
             geo[6] += fabsf(vx);
             geo[7] += fabsf(vy);
           }
-          red[NQ * 68 + lane] = quad_fold_rows(geo[0], geo[1], geo[2], geo[3]);
-          red[(NQ + 1) * 68 + lane] = quad_fold_rows(geo[4], geo[5], geo[6], geo[7]);
+          red[NQR * 68 + lane] = quad_fold_rows(geo[0], geo[1], geo[2], geo[3]);
+          red[(NQR + 1) * 68 + lane] = quad_fold_rows(geo[4], geo[5], geo[6], geo[7]);
         }
       };
       // A Gaussian that only reaches the upper or the lower half of the tile (38 % of the contributing pairs
@@ -310,11 +318,11 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
           const f2 s2 = f2{p2.x, p2.y} + f2{p2.z, p2.w}, s3 = f2{p3.x, p3.y} + f2{p3.z, p3.w};
           const f2 u = (s0 + s1) + (s2 + s3);
           const float v = u[0] + u[1];
-          if (k < CDP) {
+          if (k < CDR) {
             float *dst = gcol[k0 / WAVE];
             if (dst) atomic_add_noret(dst + (int64_t)(gshared[k0 / WAVE] ? gid - cam_first : gid) * gld[k0 / WAVE], v);
           } else if (GEOM) {
-            const int gi = k - CDP;
+            const int gi = k - CDR;
             const float sc = (k0 == 0) ? gscale
                                        : ((gi == 0 || gi == 1) ? -LN2
                                           : (gi == 2 || gi == 4) ? 0.5f
@@ -345,7 +353,7 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
 #endif
 }
 
-template <int TS, int PPL, int CD, bool GEOM>
+template <int TS, int PPL, int CD, bool GEOM, bool CGRAD>
 static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const ColorSegs &cs,
                       const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
                       const int32_t *isect_offsets, const int32_t *tile_order, const int32_t *flatten_ids,
@@ -355,7 +363,7 @@ static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, con
                       float *v_geom, const GradSegs &gs, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
   const unsigned grid = (unsigned)((n_regions + WPB - 1) / WPB);
-  hipLaunchKernelGGL((raster_bwd_kernel<TS, PPL, CD, GEOM>), dim3(grid), dim3(64 * WPB), 0, stream, (int)n_regions, N, D,
+  hipLaunchKernelGGL((raster_bwd_kernel<TS, PPL, CD, GEOM, CGRAD>), dim3(grid), dim3(64 * WPB), 0, stream, (int)n_regions, N, D,
                      ch_off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h,
                      isect_offsets, tile_order, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel,
                      v_render_colors, v_render_alphas, absgrad, v_geom, gs);
@@ -422,8 +430,9 @@ extern "C" int pr_max_channels(void) { return 100; }
       v_render_alphas, absgrad, v_geom, gs, (hipStream_t)stream
 #define BWD_CASE(TS, PPL, CDV)                                      \
   case CDV:                                                         \
-    rc = geom_grad ? launch_bwd<TS, PPL, CDV, true>(BWD_ARGS)       \
-                   : launch_bwd<TS, PPL, CDV, false>(BWD_ARGS);     \
+    rc = !geom_grad       ? launch_bwd<TS, PPL, CDV, false, true>(BWD_ARGS) \
+         : any_color_grad ? launch_bwd<TS, PPL, CDV, true, true>(BWD_ARGS)  \
+                          : launch_bwd<TS, PPL, CDV, true, false>(BWD_ARGS); \
     break;
 
 extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,

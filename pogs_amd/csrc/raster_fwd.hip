@@ -195,17 +195,18 @@ __device__ __forceinline__ f16v mfma_bf16(const unsigned (&a)[4], const unsigned
                                                  __builtin_bit_cast(bf8v, u4v{b[0], b[1], b[2], b[3]}), c, 0, 0, 0);
 }
 
-template <int CD>
+// PPL: pixels per lane (1: quarter tile per wavefront, 2: half tile); NM: 32-channel blocks on the matrix cores.
+template <int PPL, int CD, int NM>
 __global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
     const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
     const int32_t *__restrict__ tile_order, const int32_t *__restrict__ flatten_ids, int n_isects, int ed_channel,
     float *__restrict__ render_colors, float *__restrict__ render_alphas, int32_t *__restrict__ last_ids) {
-  constexpr int PPL = 2, GS = 16;        // pixels per lane; Gaussians per matrix product
+  constexpr int GS = 16;                 // Gaussians per matrix product
   using Rg = Region<16, PPL>;
   constexpr int ROW = color_row(CD), CDP = round4(CD), BS = batch_size(PPL);
-  constexpr int CM = 32;                 // channels on the matrix cores
+  constexpr int CM = 32 * NM;            // channels on the matrix cores
   constexpr int CV = CDP - CM, CV2 = CV / 2;  // channels on the vector ALU
   static_assert(CD >= CM && CV >= 0 && CV <= 16, "pass width");
   __shared__ WaveLds<CD, false, BS> L;
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
   // still accepts Gaussians, 0 once it is saturated or if it lies outside the image -- every test on "is this
   // pixel finished" is then arithmetic on Tl (a weight alpha * Tl of 0) instead of a flag carried per pixel.
   float T[PPL], Tl[PPL];
-  f16v acc[PPL][2];                      // [pixel slot][lane half of the pixel]: 32 channels x 32 pixels each
+  f16v acc[PPL][2][NM];                  // [pixel slot][lane half of the pixel][channel block]: 32 ch x 32 px each
   f2 accv[PPL][CV2 > 0 ? CV2 : 1];
   int last[PPL];
   bool inside[PPL];
@@ -242,7 +243,9 @@ __global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][hh][r] = 0.f;
+      for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][hh][mt][r] = 0.f;
 #pragma unroll
     for (int k = 0; k < (CV2 > 0 ? CV2 : 1); ++k) accv[j][k] = splat(0.f);
   }
@@ -259,10 +262,12 @@ __global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
     pre = prefetch_batch(lane, first + BS, min(BS, range_hi - first - BS), flatten_ids, means2d, conics, opacities);
     while (todo) {
       unsigned wh[PPL][GS / 2], wl[PPL][GS / 2];  // packed weights: [slot][i] = Gaussians 2i, 2i+1 of the group
-      float ca[GS / 2];                           // A operand, this lane's k half: colour mc of members 8 mh + i
+      float ca[NM][GS / 2];                       // A operands, this lane's k half: colour 32 mt + mc of members 8 mh + i
       bool any = false;
 #pragma unroll
-      for (int i = 0; i < GS / 2; ++i) ca[i] = 0.f;
+      for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+        for (int i = 0; i < GS / 2; ++i) ca[mt][i] = 0.f;
 #pragma unroll
       for (int s = 0; s < GS; s += 2) {
         float w[PPL][2];
@@ -276,9 +281,10 @@ __global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
             todo &= todo - 1;
           }
           if (t < 0) continue;
-          {  // lanes of half mh carry members 8 mh .. 8 mh + 7 of the group in the A operand
-            const float c = L.col[t * ROW + mc];
-            ca[(s + u) & 7] = (mh == ((s + u) >> 3)) ? c : ca[(s + u) & 7];
+#pragma unroll
+          for (int mt = 0; mt < NM; ++mt) {  // lanes of half mh carry members 8 mh .. 8 mh + 7 of the group in the A operand
+            const float c = L.col[t * ROW + 32 * mt + mc];
+            ca[mt][(s + u) & 7] = (mh == ((s + u) >> 3)) ? c : ca[mt][(s + u) & 7];
           }
           const float4 g = L.g4[t];
           const float2 h = L.g2[t];
@@ -330,10 +336,12 @@ __global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
         }
       }
       if (__builtin_amdgcn_ballot_w64(any) != 0ull) {
-        // A operand: row = channel mc, k = group members 8 mh .. 8 mh + 7
-        unsigned ah[4], al[4];
+        // A operands: row = channel 32 mt + mc, k = group members 8 mh .. 8 mh + 7
+        unsigned ah[NM][4], al[NM][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) split_pair(ca[2 * i], ca[2 * i + 1], ah[i], al[i]);
+        for (int mt = 0; mt < NM; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) split_pair(ca[mt][2 * i], ca[mt][2 * i + 1], ah[mt][i], al[mt][i]);
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
           unsigned b0h[4], b1h[4], b0l[4], b1l[4];
@@ -342,12 +350,15 @@ __global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
             swap32(wh[j][i], wh[j][4 + i], b0h[i], b1h[i]);
             swap32(wl[j][i], wl[j][4 + i], b0l[i], b1l[i]);
           }
-          acc[j][0] = mfma_bf16(ah, b0h, acc[j][0]);
-          acc[j][1] = mfma_bf16(ah, b1h, acc[j][1]);
-          acc[j][0] = mfma_bf16(al, b0h, acc[j][0]);
-          acc[j][1] = mfma_bf16(al, b1h, acc[j][1]);
-          acc[j][0] = mfma_bf16(ah, b0l, acc[j][0]);
-          acc[j][1] = mfma_bf16(ah, b1l, acc[j][1]);
+#pragma unroll
+          for (int mt = 0; mt < NM; ++mt) {
+            acc[j][0][mt] = mfma_bf16(ah[mt], b0h, acc[j][0][mt]);
+            acc[j][1][mt] = mfma_bf16(ah[mt], b1h, acc[j][1][mt]);
+            acc[j][0][mt] = mfma_bf16(al[mt], b0h, acc[j][0][mt]);
+            acc[j][1][mt] = mfma_bf16(al[mt], b1h, acc[j][1][mt]);
+            acc[j][0][mt] = mfma_bf16(ah[mt], b0l, acc[j][0][mt]);
+            acc[j][1][mt] = mfma_bf16(ah[mt], b1l, acc[j][1][mt]);
+          }
         }
       }
       if (all_done) break;
@@ -369,12 +380,13 @@ __global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
       float *out = render_colors + pix * D + ch_off;
       const float inv = 1.f / fmaxf(1.f - Tp, 1e-10f);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c0 = 8 * q + 4 * mh;  // channels c0 .. c0+3 of the pass sit in registers 4q .. 4q+3
+      for (int mq = 0; mq < 4 * NM; ++mq) {
+        const int mt = mq / 4, q = mq % 4;
+        const int c0 = 32 * mt + 8 * q + 4 * mh;  // channels c0 .. c0+3 of the pass sit in registers 4q .. 4q+3
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          v[i] = acc[j][hh][4 * q + i];
+          v[i] = acc[j][hh][mt][4 * q + i];
           if (backgrounds && c0 + i < nch) v[i] = fmaf(Tp, backgrounds[(int64_t)cam * D + ch_off + c0 + i], v[i]);
           if (c0 + i + ch_off == ed_channel) v[i] *= inv;
         }
@@ -422,14 +434,14 @@ __global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
   }
 }
 
-template <int CD>
+template <int PPL, int CD, int NM>
 static int launch_fwd_mfma(int C, int N, int D, int ch_off, const float *means2d, const float *conics,
                            const ColorSegs &cs, const float *opacities, const float *backgrounds, int width, int height,
                            int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
                            const int32_t *flatten_ids, int64_t n_isects, int ed_channel, float *render_colors,
                            float *render_alphas, int32_t *last_ids, hipStream_t stream) {
-  const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<16, 2>::WPT;
-  hipLaunchKernelGGL((raster_fwd_mfma_kernel<CD>), dim3((unsigned)n_regions), dim3(64), 0, stream, (int)n_regions, N, D,
+  const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<16, PPL>::WPT;
+  hipLaunchKernelGGL((raster_fwd_mfma_kernel<PPL, CD, NM>), dim3((unsigned)n_regions), dim3(64), 0, stream, (int)n_regions, N, D,
                      ch_off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
                      tile_order, flatten_ids, (int)n_isects, ed_channel, render_colors, render_alphas, last_ids);
   return check_launch("raster_fwd_mfma_kernel");
@@ -542,11 +554,22 @@ extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const fl
         FWD_CASE(16, 4, 4) FWD_CASE(16, 4, 8) FWD_CASE(16, 4, 16) FWD_CASE(16, 4, 24) FWD_CASE(16, 4, 32)
         FWD_CASE(16, 4, 36) FWD_CASE(16, 4, 48)
       }
-    } else if (plan.ppl == 2 && use_mfma && (cd == 32 || cd == 36 || cd == 48)) {
-      switch (cd) {
-        case 32: rc = launch_fwd_mfma<32>(FWD_ARGS); break;
-        case 36: rc = launch_fwd_mfma<36>(FWD_ARGS); break;
-        case 48: rc = launch_fwd_mfma<48>(FWD_ARGS); break;
+    } else if (use_mfma && cd >= 32 && ((plan.ppl == 2 && cd <= 48) || (plan.ppl == 1 && cd <= 72))) {
+      // 32 or 64 channels of the pass on the matrix cores, the remaining 0..16 on the vector ALU
+      if (plan.ppl == 2) {
+        switch (cd) {
+          case 32: rc = launch_fwd_mfma<2, 32, 1>(FWD_ARGS); break;
+          case 36: rc = launch_fwd_mfma<2, 36, 1>(FWD_ARGS); break;
+          case 48: rc = launch_fwd_mfma<2, 48, 1>(FWD_ARGS); break;
+        }  // 64 channel blocks at 2 pixels per lane would need 128 accumulators + 160 registers: one wave per SIMD
+      } else {
+        switch (cd) {
+          case 32: rc = launch_fwd_mfma<1, 32, 1>(FWD_ARGS); break;
+          case 36: rc = launch_fwd_mfma<1, 36, 1>(FWD_ARGS); break;
+          case 48: rc = launch_fwd_mfma<1, 48, 1>(FWD_ARGS); break;
+          case 64: rc = launch_fwd_mfma<1, 64, 2>(FWD_ARGS); break;
+          case 72: rc = launch_fwd_mfma<1, 72, 2>(FWD_ARGS); break;
+        }
       }
     } else if (plan.ppl == 2) {
       switch (cd) {
