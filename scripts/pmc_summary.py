@@ -8,7 +8,7 @@ import csv
 import json
 import sys
 
-ENTRY = {"raster_bwd_kernel": "pr_raster_bwd", "raster_fwd_kernel": "pr_raster_fwd", "sh_fwd_kernel": "pr_sh_fwd",
+ENTRY = {"raster_bwd_kernel": "pr_raster_bwd", "raster_fwd_kernel": "pr_raster_fwd", "raster_fwd_mfma_kernel": "pr_raster_fwd", "sh_fwd_kernel": "pr_sh_fwd",
          "sh_bwd_kernel": "pr_sh_bwd", "project_fwd_kernel": "pr_project_fwd", "project_bwd_kernel": "pr_project_bwd",
          "isect_emit_tight_kernel": "isect_emit_tight_kernel", "isect_count_tight_kernel": "isect_count_tight_kernel"}
 
