@@ -9,7 +9,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from pogs_amd import rendering, tracking  # noqa: E402
+from pogs_amd import mlp, rendering, tracking  # noqa: E402
 from pogs_amd.scenes import make_scene  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -66,7 +66,9 @@ def training_shape(n, w, h, f, ts=16, iters=10, warmup=3):
 def tracking_loop(n=200_000, w=640, h=360, groups=4, iters=50, frames=3):
     """cfg3: per frame `iters` pose-optimisation iterations; each renders RGB+ED (SH degree 3, tile 8) and a
     64-channel feature image (tile 16, geometry other than the means detached) of the object's Gaussians
-    after a per-group rigid transform, back-propagates an L2 loss to the [G,7] pose deltas, Adam step.
+    after a per-group rigid transform, pushes the feature image through the frozen 4-layer channel MLP
+    (pogs/pogs.py:516-520; fused kernel, POGS_BENCH_TORCH_MLP=1 for the torch operators), back-propagates an L2
+    loss to the [G,7] pose deltas, Adam step.
     The rigid transform (the reference's Warp kernel, pogs/tracking/utils.py:53-93) is pr_rigid_fwd/bwd; set
     POGS_BENCH_TORCH_RIGID=1 to time the plain-torch formulation (one-hot GEMM gather) instead."""
     sc = make_scene(n, w, h, n_features=64, seed=0)
@@ -82,12 +84,23 @@ def tracking_loop(n=200_000, w=640, h=360, groups=4, iters=50, frames=3):
     p2w[:, :3] = torch.randn(groups, 3, device=dev) * 0.3
     labels32 = labels.int()
     torch_rigid = os.environ.get("POGS_BENCH_TORCH_RIGID") == "1"
+    torch_mlp = os.environ.get("POGS_BENCH_TORCH_MLP") == "1"
+    net = mlp.FeatureMLP(device=dev)
+    for prm in net.parameters():
+        prm.requires_grad_(False)
+
+    def project(f, a):
+        if not torch_mlp:
+            return net(f, a)
+        x = torch.where(a > 0, f / a.clamp(min=1e-6).detach(), torch.zeros(64, device=dev))
+        return torch.nn.Sequential.forward(net, x.view(-1, 64)).view(f.shape)
     deltas.requires_grad_(True)
     opt = torch.optim.Adam([deltas], lr=1e-3)
     with torch.no_grad():
         tgt_rgb, _, _ = rendering.rasterization(means, quats, scales, opac, sh, vm, K, w, h, sh_degree=3,
                                                 render_mode="RGB+ED", packed=False, tile_size=8)
-        tgt_f, _, _ = rendering.rasterization(means, quats, scales, opac, feats, vm, K, w, h, packed=False)
+        tgt_f, tgt_a, _ = rendering.rasterization(means, quats, scales, opac, feats, vm, K, w, h, packed=False)
+        tgt_f = project(tgt_f, tgt_a)
 
     def iteration():
         opt.zero_grad(set_to_none=True)
@@ -100,8 +113,8 @@ def tracking_loop(n=200_000, w=640, h=360, groups=4, iters=50, frames=3):
             m, q = tracking.apply_to_model(p2w, deltas, labels32, means, quats)
         rgb, _, _ = rendering.rasterization(m, q, scales, opac, sh, vm, K, w, h, sh_degree=3, render_mode="RGB+ED",
                                             packed=False, tile_size=8)
-        f, _, _ = rendering.rasterization(m, q.detach(), scales, opac, feats, vm, K, w, h, packed=False)
-        loss = (rgb - tgt_rgb).square().mean() + (f - tgt_f).square().mean()
+        f, fa, _ = rendering.rasterization(m, q.detach(), scales, opac, feats, vm, K, w, h, packed=False)
+        loss = (rgb - tgt_rgb).square().mean() + (project(f, fa) - tgt_f).square().mean()
         loss.backward()
         opt.step()
 
@@ -111,7 +124,7 @@ def tracking_loop(n=200_000, w=640, h=360, groups=4, iters=50, frames=3):
 
     ms = timed(frame, frames, 1)
     return {"gaussians": n, "size": [w, h], "iters_per_frame": iters, "ms_per_frame": ms, "ms_per_iter": ms / iters,
-            "rigid": "torch" if torch_rigid else "pr_rigid"}
+            "rigid": "torch" if torch_rigid else "pr_rigid", "mlp": "torch" if torch_mlp else "pr_mlp"}
 
 
 if __name__ == "__main__":
