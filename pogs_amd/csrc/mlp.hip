@@ -6,8 +6,8 @@
 // upstream of the render with the weights frozen, as the tracker does -- its gradient with respect to the
 // rendered features.
 //
-// Arithmetic: exact float32.  v_mfma_f32_32x32x2_f32 is bit for bit an fmaf chain in k order, so the result
-// differs from torch's sgemm only by summation order.  The activations stay in registers from the first layer
+// Arithmetic, two variants.  Exact float32: v_mfma_f32_32x32x2_f32 is bit for bit an fmaf chain in k order, so the
+// result differs from torch's sgemm only by summation order.  Split bf16 (default, see below): 8x the matrix rate.  The activations stay in registers from the first layer
 // to the last, kept TRANSPOSED: a 32 (features) x 32 (pixels) MFMA result has the pixel on the lane and the
 // feature in the register index, which is exactly the B-operand layout of the next layer's product
 // H_out^T = W . H_in^T (sum over H_in^T's row index): no lane movement, no LDS round trip between layers.
@@ -19,7 +19,8 @@
 // Bound: matrix cores.  4 layers x 64 x 64 x 2 = 32.8 kFLOP per pixel at the f32 MFMA rate (64 FLOP/clk/SIMD).
 // Workgroups walk pixel groups persistently so the 64 KB of weights are staged once per workgroup; two
 // workgroups of eight wavefronts per CU (4 wavefronts per SIMD) keep the matrix pipe fed while other
-// wavefronts load, normalise and store.  Measured: 0.69 ms for a 1080p image, 99 TFLOP/s.
+// wavefronts load, normalise and store.  Measured for a 1080p image: float32 0.69 ms (99 TFLOP/s, matrix-bound),
+// split bf16 0.345 ms (516 B/pixel -> 3.1 TB/s: conversions, ReLU bookkeeping and HBM, no longer the matrix pipe).
 #include <stdlib.h>
 
 #include "common.h"
@@ -78,6 +79,84 @@ __device__ __forceinline__ void layer_product(const float *lds_layer, int lane, 
     }
 }
 
+// ---- split-bf16 variant --------------------------------------------------------------------------------------
+// Each product is done as hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_bf16 (operands = bf16 head + bf16 residual:
+// 16 mantissa bits, error <= 2^-16 per product) at 8x the f32 matrix rate.  The register layout of the activations
+// is unchanged: a k step of the next product takes registers 8s .. 8s+7 of a feature tile as they are, because
+// the order of the summation index is free -- the weights are staged in LDS in the matching order, already split,
+// as [layer][out tile][k step][lane]{hi, lo} (16 bytes each): element i of lane (m, h) at k step (kt, s) is
+// W[32 mo + m][32 kt + feature(8 s + i, h)],  feature(r, h) = 8 (r >> 2) + 4 h + (r & 3).
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo) {
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a, b}, bf2v));
+  const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2v{a - ha, b - hb}, bf2v));
+}
+
+template <bool TRANSPOSE, int BLOCK>
+__device__ __forceinline__ void stage_weights_bf16(float *lds_f, const Weights &W) {
+  unsigned *lds = reinterpret_cast<unsigned *>(lds_f);
+  // one thread per (layer, out tile, k step, lane, element pair): 4 * 2 * 4 * 64 * 4 = 8192 pairs
+  for (int idx = threadIdx.x; idx < LAYERS * 2 * 4 * 64 * 4; idx += BLOCK) {
+    const int pair = idx & 3, lane = (idx >> 2) & 63, kk = (idx >> 8) & 3, mo = (idx >> 10) & 1, l = idx >> 11;
+    const float *__restrict__ w = l == 0 ? W.w0 : l == 1 ? W.w1 : l == 2 ? W.w2 : W.w3;
+    const int m = 32 * mo + (lane & 31), h = lane >> 5;
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r = 8 * (kk & 1) + 2 * pair + e;
+      const int k = 32 * (kk >> 1) + 8 * (r >> 2) + 4 * h + (r & 3);
+      v[e] = TRANSPOSE ? w[k * DIM + m] : w[m * DIM + k];
+    }
+    unsigned hi, lo;
+    split_pair(v[0], v[1], hi, lo);
+    const int base = ((((l * 2 + mo) * 4 + kk) * 64 + lane) * 2) * 4;  // in 32-bit words: {hi[4], lo[4]}
+    lds[base + pair] = hi;
+    lds[base + 4 + pair] = lo;
+  }
+}
+
+template <int PT>
+__device__ __forceinline__ void layer_product_bf16(const float *lds_f, int layer, int lane, const f16v (&in)[PT][2],
+                                                   f16v (&out)[PT][2]) {
+  const u4v *lds = reinterpret_cast<const u4v *>(lds_f);
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[pt][mt][r] = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    bf8v ah[2], al[2];
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo) {
+      const int at = (((layer * 2 + mo) * 4 + kk) * 64 + lane) * 2;
+      ah[mo] = __builtin_bit_cast(bf8v, lds[at]);
+      al[mo] = __builtin_bit_cast(bf8v, lds[at + 1]);
+    }
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+      unsigned bh[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        split_pair(in[pt][kk >> 1][8 * (kk & 1) + 2 * i], in[pt][kk >> 1][8 * (kk & 1) + 2 * i + 1], bh[i], bl[i]);
+      const bf8v vh = __builtin_bit_cast(bf8v, u4v{bh[0], bh[1], bh[2], bh[3]});
+      const bf8v vl = __builtin_bit_cast(bf8v, u4v{bl[0], bl[1], bl[2], bl[3]});
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo) {
+        out[pt][mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mo], vh, out[pt][mo], 0, 0, 0);
+        out[pt][mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mo], vh, out[pt][mo], 0, 0, 0);
+        out[pt][mo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mo], vl, out[pt][mo], 0, 0, 0);
+      }
+    }
+  }
+}
+
 // Rows of a [P, 64] image <-> the transposed register layout; pixels past P read as zero and are not written.
 template <int PT>
 __device__ __forceinline__ void load_rows(const float *__restrict__ src, int64_t first_pixel, int64_t P, int lane,
@@ -120,13 +199,14 @@ __device__ __forceinline__ void store_rows(float *__restrict__ dst, int64_t firs
 // masks[(tile * 64 + lane) * 3 + layer] as 32-bit words; the backward kernel reads them back in the same layout.
 // PT: 32-pixel tiles per wavefront; WPE: wavefronts per SIMD the register budget is sized for; HOIST: let the
 // compiler keep all four weight matrices in registers across the persistent loop (256 registers, WPE = 1).
-template <int PT, int WPE, int BLOCK, bool HOIST>
+template <int PT, int WPE, int BLOCK, bool HOIST, bool BF16>
 __global__ void __launch_bounds__(BLOCK, WPE) mlp_fwd_kernel(int64_t P, const float *__restrict__ feats,
                                                         const float *__restrict__ alphas, const Weights W,
                                                         float zero_below, float *__restrict__ out,
                                                         unsigned *__restrict__ masks) {
   extern __shared__ float lds[];
-  stage_weights<false, BLOCK>(lds, W);
+  if (BF16) stage_weights_bf16<false, BLOCK>(lds, W);
+  else stage_weights<false, BLOCK>(lds, W);
   constexpr int PIX_PER_WAVE = 32 * PT;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -146,18 +226,20 @@ __global__ void __launch_bounds__(BLOCK, WPE) mlp_fwd_kernel(int64_t P, const fl
       for (int pt = 0; pt < PT; ++pt) {
         const int64_t pix = first + pt * 32 + (lane & 31);
         al[pt] = pix < P ? alphas[pix] : 0.f;
-        const float d = fmaxf(al[pt], 1e-6f);
+        const float d = fmaxf(al[pt], 1e-6f), inv = al[pt] > 0.f ? 1.f / d : 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) a[pt][kt][r] = al[pt] > 0.f ? a[pt][kt][r] / d : 0.f;
+          for (int r = 0; r < 16; ++r)  // float32: true division, as torch; split-bf16: one reciprocal (1 ulp)
+            a[pt][kt][r] = BF16 ? a[pt][kt][r] * inv : (al[pt] > 0.f ? a[pt][kt][r] / d : 0.f);
       }
     }
 #pragma unroll
     for (int l = 0; l < LAYERS; ++l) {
       f16v(&src)[PT][2] = (l & 1) ? b : a;
       f16v(&dst)[PT][2] = (l & 1) ? a : b;
-      layer_product<PT>(lds + l * DIM * DIM, lane, src, dst);
+      if (BF16) layer_product_bf16<PT>(lds, l, lane, src, dst);
+      else layer_product<PT>(lds + l * DIM * DIM, lane, src, dst);
       if (l < LAYERS - 1) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
@@ -188,14 +270,15 @@ __global__ void __launch_bounds__(BLOCK, WPE) mlp_fwd_kernel(int64_t P, const fl
   }
 }
 
-template <int PT, int WPE, int BLOCK, bool HOIST>
+template <int PT, int WPE, int BLOCK, bool HOIST, bool BF16>
 __global__ void __launch_bounds__(BLOCK, WPE) mlp_bwd_input_kernel(int64_t P, const float *__restrict__ v_out,
                                                               const float *__restrict__ alphas, const Weights W,
                                                               float zero_below,
                                                               const unsigned *__restrict__ masks,
                                                               float *__restrict__ v_feats) {
   extern __shared__ float lds[];
-  stage_weights<true, BLOCK>(lds, W);
+  if (BF16) stage_weights_bf16<true, BLOCK>(lds, W);
+  else stage_weights<true, BLOCK>(lds, W);
   constexpr int PIX_PER_WAVE = 32 * PT;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -223,7 +306,8 @@ __global__ void __launch_bounds__(BLOCK, WPE) mlp_bwd_input_kernel(int64_t P, co
     for (int l = LAYERS - 1; l >= 0; --l) {
       f16v(&src)[PT][2] = ((LAYERS - 1 - l) & 1) ? b : a;
       f16v(&dst)[PT][2] = ((LAYERS - 1 - l) & 1) ? a : b;
-      layer_product<PT>(lds + l * DIM * DIM, lane, src, dst);
+      if (BF16) layer_product_bf16<PT>(lds, l, lane, src, dst);
+      else layer_product<PT>(lds + l * DIM * DIM, lane, src, dst);
       if (l > 0) {  // through the ReLU of layer l - 1
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
@@ -239,11 +323,12 @@ __global__ void __launch_bounds__(BLOCK, WPE) mlp_bwd_input_kernel(int64_t P, co
     if (alphas) {
 #pragma unroll
       for (int pt = 0; pt < PT; ++pt) {
-        const float d = fmaxf(al[pt], 1e-6f);
+        const float d = fmaxf(al[pt], 1e-6f), inv = al[pt] > 0.f ? 1.f / d : 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) a[pt][kt][r] = al[pt] > 0.f ? a[pt][kt][r] / d : 0.f;
+          for (int r = 0; r < 16; ++r)  // float32: true division, as torch; split-bf16: one reciprocal (1 ulp)
+            a[pt][kt][r] = BF16 ? a[pt][kt][r] * inv : (al[pt] > 0.f ? a[pt][kt][r] / d : 0.f);
       }
     }
     store_rows<PT>(v_feats, first, P, lane, a);
@@ -252,18 +337,20 @@ __global__ void __launch_bounds__(BLOCK, WPE) mlp_bwd_input_kernel(int64_t P, co
 
 struct Variant {
   int pt, wpe, block;
-  bool hoist;
+  bool hoist, bf16;
 };
-// POGS_MLP_VARIANT = 0..3 selects a kernel shape (for measurements); the default is the fastest measured.
+// POGS_MLP_VARIANT selects a kernel shape and arithmetic (read per call, for measurements and tests):
+// 0-3 exact float32 (v_mfma_f32_32x32x2_f32), 4-6 split bf16 (3 x v_mfma_f32_32x32x16_bf16 per product).
+constexpr int N_VARIANTS = 7, DEFAULT_VARIANT = 4;
 Variant variant() {
-  // measured on a 1080p image, forward: 0.725 / 0.688 / 0.701 / 0.802 ms
-  static const Variant table[] = {{1, 2, 256, false}, {1, 4, 512, false}, {2, 2, 256, false}, {2, 1, 256, true}};
-  static const int chosen = [] {
-    const char *e = getenv("POGS_MLP_VARIANT");
-    const int v = e ? atoi(e) : 1;
-    return v >= 0 && v < 4 ? v : 1;
-  }();
-  return table[chosen];
+  // measured on a 1080p image, forward: 0.725 / 0.688 / 0.701 / 0.802 ms (float32)
+  static const Variant table[N_VARIANTS] = {{1, 2, 256, false, false}, {1, 4, 512, false, false},
+                                            {2, 2, 256, false, false}, {2, 1, 256, true, false},
+                                            {1, 4, 512, false, true},  {2, 2, 256, false, true},
+                                            {1, 2, 256, false, true}};
+  const char *e = getenv("POGS_MLP_VARIANT");
+  const int v = e && *e ? atoi(e) : DEFAULT_VARIANT;
+  return table[v >= 0 && v < N_VARIANTS ? v : DEFAULT_VARIANT];
 }
 
 int grid_for(int64_t P, const Variant &v) {
@@ -306,14 +393,17 @@ extern "C" int pr_mlp_fwd(int64_t n_pixels, const float *feats, const float *alp
   const pr::Variant v = pr::variant();
   hipStream_t st = (hipStream_t)stream;
   unsigned *m = (unsigned *)masks;
-#define PR_MLP_CASE(PT, WPE, BLK, HOIST)                                                                        \
-  if (v.pt == PT && v.wpe == WPE && v.block == BLK && v.hoist == HOIST)                                         \
-    return pr::launch(pr::mlp_fwd_kernel<PT, WPE, BLK, HOIST>, "pr_mlp_fwd", n_pixels, v, st, feats, alphas, W, \
+#define PR_MLP_CASE(PT, WPE, BLK, HOIST, BF)                                                                    \
+  if (v.pt == PT && v.wpe == WPE && v.block == BLK && v.hoist == HOIST && v.bf16 == BF)                         \
+    return pr::launch(pr::mlp_fwd_kernel<PT, WPE, BLK, HOIST, BF>, "pr_mlp_fwd", n_pixels, v, st, feats, alphas, W, \
                       zero_below, out, m);
-  PR_MLP_CASE(1, 2, 256, false)
-  PR_MLP_CASE(1, 4, 512, false)
-  PR_MLP_CASE(2, 2, 256, false)
-  PR_MLP_CASE(2, 1, 256, true)
+  PR_MLP_CASE(1, 2, 256, false, false)
+  PR_MLP_CASE(1, 4, 512, false, false)
+  PR_MLP_CASE(2, 2, 256, false, false)
+  PR_MLP_CASE(2, 1, 256, true, false)
+  PR_MLP_CASE(1, 4, 512, false, true)
+  PR_MLP_CASE(2, 2, 256, false, true)
+  PR_MLP_CASE(1, 2, 256, false, true)
 #undef PR_MLP_CASE
   return PR_EUNSUPPORTED;
 }
@@ -329,14 +419,17 @@ extern "C" int pr_mlp_bwd_input(int64_t n_pixels, const float *v_out, const floa
   const pr::Variant v = pr::variant();
   hipStream_t st = (hipStream_t)stream;
   const unsigned *m = (const unsigned *)masks;
-#define PR_MLP_CASE(PT, WPE, BLK, HOIST)                                                                       \
-  if (v.pt == PT && v.wpe == WPE && v.block == BLK && v.hoist == HOIST)                                        \
-    return pr::launch(pr::mlp_bwd_input_kernel<PT, WPE, BLK, HOIST>, "pr_mlp_bwd_input", n_pixels, v, st, v_out, \
+#define PR_MLP_CASE(PT, WPE, BLK, HOIST, BF)                                                                   \
+  if (v.pt == PT && v.wpe == WPE && v.block == BLK && v.hoist == HOIST && v.bf16 == BF)                        \
+    return pr::launch(pr::mlp_bwd_input_kernel<PT, WPE, BLK, HOIST, BF>, "pr_mlp_bwd_input", n_pixels, v, st, v_out, \
                       alphas, W, zero_below, m, v_feats);
-  PR_MLP_CASE(1, 2, 256, false)
-  PR_MLP_CASE(1, 4, 512, false)
-  PR_MLP_CASE(2, 2, 256, false)
-  PR_MLP_CASE(2, 1, 256, true)
+  PR_MLP_CASE(1, 2, 256, false, false)
+  PR_MLP_CASE(1, 4, 512, false, false)
+  PR_MLP_CASE(2, 2, 256, false, false)
+  PR_MLP_CASE(2, 1, 256, true, false)
+  PR_MLP_CASE(1, 4, 512, false, true)
+  PR_MLP_CASE(2, 2, 256, false, true)
+  PR_MLP_CASE(1, 2, 256, false, true)
 #undef PR_MLP_CASE
   return PR_EUNSUPPORTED;
 }

@@ -1,9 +1,12 @@
-"""Fused channel MLP on the rendered feature image (MI355X matrix cores, exact float32).
+"""Fused channel MLP on the rendered feature image (MI355X matrix cores).
 
 Replaces, in the model's ``get_outputs`` (``pogs/pogs.py:516-522``), the alpha normalisation, the call of
 ``self.nn`` (four bias-free 64-wide ``Linear`` layers with ReLU between, ``pogs/pogs.py:153-161``) and the
 eval-mode cut below alpha 0.8 with one kernel that reads the feature image once and writes the result once;
-the intermediate activations never reach memory.
+the intermediate activations never reach memory.  Arithmetic: split-bf16 by default (each float32 product as
+three bf16 matrix products, error 2^-16 per product: 1e-4 of the output scale, the tolerance the rendered image
+itself is held to); ``POGS_MLP_VARIANT=1`` selects the exact-float32 matrix instruction (summation order is the
+only difference from torch).
 
 ``FeatureMLP`` is the reference module itself with another ``forward``: its ``state_dict`` keys are ``0.weight``,
 ``2.weight``, ``4.weight``, ``6.weight`` like the ``torch.nn.Sequential`` it stands in for, so checkpoints

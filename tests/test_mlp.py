@@ -1,7 +1,9 @@
 """Fused channel MLP (pr_mlp_fwd / pr_mlp_bwd_input) against the torch restatement of pogs/pogs.py:153-161,516-522.
 
-Tolerance: the kernel is exact float32 with a different summation order from a float64 reference; four chained
-64-term dot products of O(1) values agree to ~1e-5 relative.  Tests state 2e-5 * scale.
+Two arithmetics (POGS_MLP_VARIANT): exact float32 MFMA -- differs from a float64 reference by summation order
+only, four chained 64-term dot products of O(1) values agree to ~1e-5 relative, bound 2e-5 * scale -- and the
+default split-bf16 (three bf16 products per float32 product, 2^-16 per product), bound 1e-4 * scale, the
+tolerance the rendered colours themselves are held to.  Gradients: 1e-3 relative in both.
 """
 import ctypes
 
@@ -10,6 +12,16 @@ import torch
 
 from oracle.mlp_ref import feature_mlp_ref
 from pogs_amd import _lib
+
+
+ARITH = {"f32": ("1", 2e-5), "bf16x3": ("4", 1e-4)}
+
+
+@pytest.fixture(params=sorted(ARITH))
+def arith(request, monkeypatch):
+    variant, tol = ARITH[request.param]
+    monkeypatch.setenv("POGS_MLP_VARIANT", variant)
+    return tol
 
 
 def _weights(gen, scale=1.0):
@@ -60,7 +72,7 @@ def test_module_is_a_sequential_with_reference_keys():
 @pytest.mark.gpu
 @pytest.mark.parametrize("P", [1, 63, 64, 65, 1000, 256 * 1024 + 17])
 @pytest.mark.parametrize("with_alpha", [False, True])
-def test_forward_parity(P, with_alpha):
+def test_forward_parity(P, with_alpha, arith):
     from pogs_amd.mlp import feature_mlp
     gen = torch.Generator().manual_seed(P)
     ws = _weights(gen, scale=3.0)
@@ -74,11 +86,11 @@ def test_forward_parity(P, with_alpha):
     ref = feature_mlp_ref(x.float().double(), None if al is None else al.float().double(), [w.float().double() for w in ws])
     got = feature_mlp(x.float().cuda(), None if al is None else al.float().cuda(), [w.float().cuda() for w in ws]).cpu()
     scale = max(ref.abs().max().item(), 1.0)
-    assert (got.double() - ref).abs().max().item() <= 2e-5 * scale
+    assert (got.double() - ref).abs().max().item() <= arith * scale
 
 
 @pytest.mark.gpu
-def test_eval_cut_and_image_shape():
+def test_eval_cut_and_image_shape(arith):
     from pogs_amd.mlp import FeatureMLP
     gen = torch.Generator().manual_seed(11)
     m = FeatureMLP(device="cuda").eval()
@@ -90,18 +102,18 @@ def test_eval_cut_and_image_shape():
     ref = feature_mlp_ref(x.double(), al.double(), ws, zero_below=0.8)
     assert got.shape == (1, 37, 53, 64)
     assert (got[al.squeeze(-1) < 0.8] == 0).all()
-    assert (got.double() - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0)
+    assert (got.double() - ref).abs().max().item() <= arith * max(ref.abs().max().item(), 1.0)
     m.train()
     with torch.no_grad():
         got = m(x.cuda(), al.cuda()).cpu()
     ref = feature_mlp_ref(x.double(), al.double(), ws)
-    assert (got.double() - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0)
+    assert (got.double() - ref).abs().max().item() <= arith * max(ref.abs().max().item(), 1.0)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("P", [65, 5000])
 @pytest.mark.parametrize("train_weights", [False, True])
-def test_backward_parity(P, train_weights):
+def test_backward_parity(P, train_weights, arith):
     """Frozen weights: the fused input-gradient kernel.  Trainable weights: input and weight gradients."""
     from pogs_amd.mlp import feature_mlp
     gen = torch.Generator().manual_seed(100 + P)
