@@ -325,6 +325,26 @@ def test_raster_forward(gpu, tile_size, D, with_bg):
     assert_image_close(alpha, alpha_r, amb, "alpha")
 
 
+@pytest.mark.parametrize("ppl,D", [(2, 32), (2, 35), (2, 36), (2, 48), (2, 97), (1, 33), (1, 36), (1, 64), (1, 68),
+                                   (1, 72)])
+@pytest.mark.parametrize("mfma", ["1", "0"])
+def test_raster_forward_matrix_core_variant(gpu, monkeypatch, ppl, D, mfma):
+    """The forward kernels that small test images never select on their own: pixels per lane forced through the
+    tuning variable, matrix-core (split-bf16 colour accumulation) and vector variants, passes of 32..72 channels
+    (D = 97 splits into several passes), with backgrounds."""
+    rd = _rendering()
+    monkeypatch.setenv("POGS_RAST_FWD_PPL", str(ppl))
+    monkeypatch.setenv("POGS_RAST_FWD_MFMA", mfma)
+    sc = small_scene(n=700, w=70, h=45, views=2, seed=5, lo=0.02, hi=0.3)
+    dev, offs, flat = _staged(gpu, sc, D, 16)
+    bg = torch.rand(2, D, generator=torch.Generator().manual_seed(2)).to(gpu)
+    out, alpha = rd.rasterize_to_pixels(dev["means2d"], dev["conics"], dev["colors"], dev["opacities"], sc.width,
+                                        sc.height, 16, offs, flat, backgrounds=bg)
+    _, out_r, alpha_r, amb = _oracle_raster(dev, offs, flat, sc, 16, bg, False)
+    assert_image_close(out, out_r, amb, f"colors D={D} ppl={ppl} mfma={mfma}")
+    assert_image_close(alpha, alpha_r, amb, "alpha")
+
+
 @pytest.mark.parametrize("tile_size,D", [(16, 4), (16, 19), (16, 36), (16, 64), (16, 97), (8, 4), (8, 64)])
 @pytest.mark.parametrize("with_bg", [False, True])
 def test_raster_backward(gpu, tile_size, D, with_bg):
