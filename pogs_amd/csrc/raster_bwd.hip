@@ -370,6 +370,222 @@ static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, con
   return check_launch("raster_bwd_kernel");
 }
 
+// ---- geometry-only backward with the dot products on the matrix cores (16x16 tiles, 1 pixel per lane) -------
+// For callers that ask for no colour gradients (the tracker) what is left per (pixel, Gaussian) is the dot product
+// S = <colour_g, v_pixel> and a handful of scalars.  S for a whole staged batch is one matrix product,
+// S^T (32 staged slots x 32 pixels) = C (32 x channels) . V^T (channels x 32 pixels) per half of the wavefront, on
+// v_mfma_f32_32x32x16_bf16 with both operands split into bf16 head + residual (hi.hi + lo.hi + hi.lo).  V^T is
+// constant for the tile: it becomes the B operand once, in the prologue (the lanes of a pixel's own registers are
+// the operand's register index; one v_permlane32_swap per register pair sorts out the two 32-pixel halves), and
+// the float32 cotangents are then dropped from the registers.  The A operand is the staged colour rows as they lie
+// in LDS (lane = slot).  16 more swaps bring S[pixel][slot] home to the pixel's lane; the back-to-front walk over
+// the slots is unrolled so that every slot's S is a fixed register.  Channels past the last full 16 stay on the
+// vector ALU.
+template <int CD>
+__global__ void __launch_bounds__(64) raster_bwd_geom_mfma_kernel(
+    int n_regions, int N, int D, const float *__restrict__ means2d, const float *__restrict__ conics,
+    const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int width,
+    int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
+    const int32_t *__restrict__ tile_order, const int32_t *__restrict__ flatten_ids, int n_isects,
+    const float *__restrict__ render_alphas, const int32_t *__restrict__ last_ids,
+    const float *__restrict__ render_colors, int ed_channel, const float *__restrict__ v_render_colors,
+    const float *__restrict__ v_render_alphas, int absgrad, float *__restrict__ v_geom) {
+  using Rg = Region<16, 1>;
+  constexpr int ROW = color_row(CD), CDP = round4(CD), BS = 32;
+  constexpr int KS = CDP / 16, CM = 16 * KS, CV = CDP - CM;  // k steps / channels on the matrix cores / on the VALU
+  static_assert(KS >= 1 && CV >= 0 && CV < 16, "pass width");
+  __shared__ WaveLds<CD, false, BS> L;
+  __shared__ float red[2 * 68];
+  const int lane = threadIdx.x & 63;
+  const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+  const int region = (int)bid;
+  if (region >= n_regions) return;
+  const int tile_flat = tile_order ? tile_order[region / Rg::WPT] : region / Rg::WPT, sub = region % Rg::WPT;
+  const int n_tiles = tile_w * tile_h;
+  const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
+  const int ty = tile / tile_w, tx = tile % tile_w;
+  const int x = tx * 16 + (lane % Rg::LX), y = ty * 16 + sub * Rg::RH + (lane / Rg::LX);
+  const int range_lo = isect_offsets[tile_flat];
+  const int nch = min(CD, D);
+  const float px0 = (float)x + 0.5f, py0 = (float)y + 0.5f;
+
+  float T = 1.f, Bsum = 0.f, W = 0.f;
+  int last = range_lo;
+  unsigned b0h[KS][4], b1h[KS][4], b0l[KS][4], b1l[KS][4];  // V^T as B operand: pixels 0-31 / 32-63, head / residual
+  float vrest[CV > 0 ? CV : 1];
+  {
+    float v[CDP];
+#pragma unroll
+    for (int k = 0; k < CDP; ++k) v[k] = 0.f;
+    if (x < width && y < height) {
+      const int64_t pix = ((int64_t)cam * height + y) * width + x;
+      T = 1.f - render_alphas[pix];
+      last = last_ids[pix];
+      const float *src = v_render_colors + pix * D;
+      if ((D & 3) == 0) {
+#pragma unroll
+        for (int k = 0; k + 3 < CDP; k += 4)
+          if (k < nch) {
+            const float4 q = *reinterpret_cast<const float4 *>(src + k);
+            v[k] = q.x, v[k + 1] = q.y, v[k + 2] = q.z, v[k + 3] = q.w;
+          }
+      } else {
+#pragma unroll
+        for (int k = 0; k < CD; ++k)
+          if (k < nch) v[k] = src[k];
+      }
+      float w_ed = 0.f;
+      if (ed_channel >= 0) {  // expected depth out_d = X / max(a, 1e-10): see raster_bwd_kernel
+        const float a = 1.f - T, inv = 1.f / fmaxf(a, 1e-10f);
+#pragma unroll
+        for (int k = 0; k < CD; ++k)
+          if (k == ed_channel) {
+            if (a > 1e-10f) w_ed = -v[k] * render_colors[pix * D + ed_channel] * inv;
+            v[k] *= inv;
+          }
+      }
+      float w = v_render_alphas[pix] + w_ed;
+      if (backgrounds) {
+        const float *bg = backgrounds + (int64_t)cam * D;
+#pragma unroll
+        for (int k = 0; k < CD; ++k)
+          if (k < nch) w -= bg[k] * v[k];
+      }
+      W = T * w;
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned xh, xl, yh, yl;
+        split_pair(v[16 * ks + 2 * i], v[16 * ks + 2 * i + 1], xh, xl);
+        split_pair(v[16 * ks + 8 + 2 * i], v[16 * ks + 9 + 2 * i], yh, yl);
+        swap32(xh, yh, b0h[ks][i], b1h[ks][i]);
+        swap32(xl, yl, b0l[ks][i], b1l[ks][i]);
+      }
+#pragma unroll
+    for (int k = 0; k < CV; ++k) vrest[k] = v[CM + k];
+  }
+  int max_last = last;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) max_last = max(max_last, __shfl_xor(max_last, m));
+
+  const int own_q = lane >> 2, own_row = ((lane & 1) << 1) | ((lane >> 1) & 1);
+  const float4 *own = reinterpret_cast<const float4 *>(red + own_q * 68 + own_row * 16);
+  const float gscale = (lane == 0 || lane == 1) ? -LN2 : (lane == 2 || lane == 4) ? 0.5f
+                       : (lane == 6 || lane == 7) ? LN2 : 1.f;
+  const int n_geo = absgrad ? 8 : 6;
+  const int mrow = lane & 31, mh = lane >> 5;
+
+  const float rx0 = (float)(tx * 16) + 0.5f, ry0 = (float)(ty * 16 + sub * Rg::RH) + 0.5f;
+  const float rx1 = (float)min(tx * 16 + 16, width) - 0.5f;
+  const float ry1 = (float)min(ty * 16 + sub * Rg::RH + Rg::RH, height) - 0.5f;
+  BatchGeometry pre = prefetch_batch(lane, max(range_lo, max_last - BS), max_last - max(range_lo, max_last - BS),
+                                     flatten_ids, means2d, conics, opacities);
+  for (int bend = max_last; bend > range_lo; bend -= BS) {
+    const int first = max(range_lo, bend - BS);
+    const unsigned long long todo = stage_batch<CD, false, BS>(L, lane, pre, cs, N, D, 0, rx0, ry0, rx1, ry1);
+    {
+      const int nend = bend - BS, nfirst = max(range_lo, nend - BS);
+      pre = prefetch_batch(lane, nfirst, nend - nfirst, flatten_ids, means2d, conics, opacities);
+    }
+    if (todo == 0ull) continue;
+    // S for every staged slot and every pixel of the region
+    f16v s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s0[r] = 0.f, s1[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 *row = reinterpret_cast<const float4 *>(L.col + mrow * ROW + 16 * ks + 8 * mh);
+      const float4 c0 = row[0], c1 = row[1];
+      unsigned ah[4], al[4];
+      split_pair(c0.x, c0.y, ah[0], al[0]);
+      split_pair(c0.z, c0.w, ah[1], al[1]);
+      split_pair(c1.x, c1.y, ah[2], al[2]);
+      split_pair(c1.z, c1.w, ah[3], al[3]);
+      s0 = mfma_bf16(ah, b0h[ks], s0);
+      s1 = mfma_bf16(ah, b1h[ks], s1);
+      s0 = mfma_bf16(al, b0h[ks], s0);
+      s1 = mfma_bf16(al, b1h[ks], s1);
+      s0 = mfma_bf16(ah, b0l[ks], s0);
+      s1 = mfma_bf16(ah, b1l[ks], s1);
+    }
+    // s0 = pixels 0-31, s1 = pixels 32-63, rows (slots) of lane half mh -> every pixel's own lane, all 32 slots:
+    // sa[r] = slot (r&3) + 8 (r>>2), sb[r] = that + 4
+    float sa[16], sb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // Written as inline assembly on purpose: hipcc (ROCm 7.2) merges the sixteen permlane32_swap builtin calls on
+      // the elements of an accumulator vector into ONE (every slot then sees slot 0's dot product).
+      float fa = s0[r], fb = s1[r];
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(fa), "+v"(fb));
+      sa[r] = fa;
+      sb[r] = fb;
+    }
+#pragma unroll
+    for (int t = BS - 1; t >= 0; --t) {
+      if (!((todo >> t) & 1ull)) continue;
+      const int idx = first + t;
+      const float4 g = L.g4[t];
+      const float2 h = L.g2[t];
+      const float dx = g.x - px0, dy = g.y - py0;
+      const float power = g.w * dx * dx + h.y * dy * dy + h.x * dx * dy;
+      const float e = __builtin_amdgcn_exp2f(power), ar = g.z * e;
+      const float a = fminf(ALPHA_MAX, ar);
+      const bool active = (power <= 0.f) && (a >= ALPHA_MIN) && (idx < last);
+      if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
+      const float alpha = active ? a : 0.f;
+      float S = ((t >> 2) & 1) ? sb[(t & 3) + 4 * (t >> 3)] : sa[(t & 3) + 4 * (t >> 3)];
+      if (CV > 0) {
+        const float4 *crow = reinterpret_cast<const float4 *>(L.col + t * ROW + CM);
+#pragma unroll
+        for (int q = 0; q < CV / 4; ++q) {
+          const float4 c = crow[q];
+          S = fmaf(c.x, vrest[4 * q], S);
+          S = fmaf(c.y, vrest[4 * q + 1], S);
+          S = fmaf(c.z, vrest[4 * q + 2], S);
+          S = fmaf(c.w, vrest[4 * q + 3], S);
+        }
+      }
+      const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+      T *= ra;
+      const float fac = alpha * T;
+      const float v_alpha = S * T - (Bsum - W) * ra;
+      Bsum = fmaf(fac, S, Bsum);
+      const float ev = (alpha == ar ? e : 0.f) * v_alpha;
+      const float vs = -g.z * ev;
+      const float t1 = vs * dx, t2 = vs * dy;
+      const float gx = 2.f * g.w * dx + h.x * dy, gy = h.x * dx + 2.f * h.y * dy;
+      const float vx = vs * gx, vy = vs * gy;
+      red[lane] = quad_fold_rows(vx, vy, t1 * dx, t1 * dy);
+      red[68 + lane] = quad_fold_rows(t2 * dy, ev, fabsf(vx), fabsf(vy));
+      const int gid = L.ids[t];
+      if (lane < 8) {
+        const float4 p0 = own[0], p1 = own[1], p2 = own[2], p3 = own[3];
+        const float tot = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w)) +
+                          ((p2.x + p2.y) + (p2.z + p2.w)) + ((p3.x + p3.y) + (p3.z + p3.w));
+        if (lane < n_geo) atomic_add_noret(v_geom + (int64_t)gid * 8 + lane, tot * gscale);
+      }
+    }
+  }
+}
+
+template <int CD>
+static int launch_bwd_geom_mfma(int C, int N, int D, const float *means2d, const float *conics, const ColorSegs &cs,
+                                const float *opacities, const float *backgrounds, int width, int height, int tile_w,
+                                int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
+                                const int32_t *flatten_ids, int64_t n_isects, const float *render_alphas,
+                                const int32_t *last_ids, const float *render_colors, int ed_channel,
+                                const float *v_render_colors, const float *v_render_alphas, int absgrad, float *v_geom,
+                                hipStream_t stream) {
+  const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<16, 1>::WPT;
+  hipLaunchKernelGGL((raster_bwd_geom_mfma_kernel<CD>), dim3((unsigned)n_regions), dim3(64), 0, stream, (int)n_regions,
+                     N, D, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
+                     tile_order, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel,
+                     v_render_colors, v_render_alphas, absgrad, v_geom);
+  return check_launch("raster_bwd_geom_mfma_kernel");
+}
+
 #ifdef PR_DIAG
 extern "C" int pr_diag_read(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pr::g_diag), sizeof(pr::g_diag)) != hipSuccess) return -4;
@@ -467,6 +683,25 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
   if (!geom_grad && !any_color_grad) return PR_OK;
   if ((int64_t)C * tile_w * tile_h * 4 > 2147483647ll) return PR_EUNSUPPORTED;
   const BwdPlan plan = plan_bwd(D, geom_grad, tile_size, (int64_t)C * tile_w * tile_h);
+  // geometry gradients only, 16x16 tiles at 1 pixel per lane: the dot products go to the matrix cores
+  if (geom_grad && !any_color_grad && tile_size == 16 && plan.ppl == 1 && env_int("POGS_RAST_BWD_MFMA", 1) != 0) {
+    const int cd = pick_chunk(D);
+#define GEOM_MFMA_ARGS                                                                                             \
+  C, N, D, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets, tile_order, \
+      flatten_ids, n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas, \
+      absgrad, v_geom, (hipStream_t)stream
+    switch (cd) {
+      case 16: return launch_bwd_geom_mfma<16>(GEOM_MFMA_ARGS);
+      case 24: return launch_bwd_geom_mfma<24>(GEOM_MFMA_ARGS);
+      case 32: return launch_bwd_geom_mfma<32>(GEOM_MFMA_ARGS);
+      case 36: return launch_bwd_geom_mfma<36>(GEOM_MFMA_ARGS);
+      case 48: return launch_bwd_geom_mfma<48>(GEOM_MFMA_ARGS);
+      case 64: return launch_bwd_geom_mfma<64>(GEOM_MFMA_ARGS);
+      case 72: return launch_bwd_geom_mfma<72>(GEOM_MFMA_ARGS);
+      default: break;  // narrower or wider passes: the vector kernels below
+    }
+#undef GEOM_MFMA_ARGS
+  }
   for (int off = 0; off < D; off += plan.per) {
     const int cd = pick_chunk(min(plan.per, D - off));
     int rc = PR_EUNSUPPORTED;

@@ -236,4 +236,28 @@ __device__ __forceinline__ unsigned long long stage_batch(
   return __builtin_amdgcn_ballot_w64(keep);
 }
 
+// ---- split-bf16 matrix-core helpers (v_mfma_f32_32x32x16_bf16: A[row l&31][k = 8(l>>5)+j], B[k = 8(l>>5)+j][col l&31],
+// C: col = l&31, row = (reg&3) + 8(reg>>2) + 4(l>>5)) ----------------------------------------------------------------
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+// (a, b) -> packed bf16 heads and packed bf16 residuals
+__device__ __forceinline__ void split_pair(float a, float b, unsigned &hi, unsigned &lo) {
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2v));
+  const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a - ha, b - hb}, bf2v));
+}
+__device__ __forceinline__ void swap32(unsigned a, unsigned b, unsigned &lo_tile, unsigned &hi_tile) {
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  lo_tile = r[0];
+  hi_tile = r[1];
+  asm("" : "+v"(lo_tile), "+v"(hi_tile));
+}
+__device__ __forceinline__ f16v mfma_bf16(const unsigned (&a)[4], const unsigned (&b)[4], f16v c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, u4v{a[0], a[1], a[2], a[3]}),
+                                                 __builtin_bit_cast(bf8v, u4v{b[0], b[1], b[2], b[3]}), c, 0, 0, 0);
+}
+
 }  // namespace pr
