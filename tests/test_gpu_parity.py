@@ -425,21 +425,23 @@ def test_raster_backward_colors_only(gpu):
         assert_grad_close(colors.grad, cpu["colors"].grad, f"colors-only D={D}")
 
 
-@pytest.mark.parametrize("tile_size,D", [(16, 4), (16, 36), (16, 64), (8, 4), (8, 64)])
+@pytest.mark.parametrize("tile_size,D", [(16, 4), (16, 16), (16, 20), (16, 36), (16, 48), (16, 64), (16, 72), (8, 4),
+                                         (8, 64)])
 def test_raster_backward_geometry_only(gpu, tile_size, D):
     """Appearance frozen (the tracker, pogs/tracking/rigid_group_optimizer.py:402-453: only poses are optimised):
     gradients of means2d, conics and opacities with no colour gradient requested."""
     rd = _rendering()
     sc = small_scene(n=600, w=70, h=45, views=2, seed=8, lo=0.02, hi=0.3)
     dev, offs, flat = _staged(gpu, sc, D, tile_size)
-    cpu, out_r, alpha_r, amb = _oracle_raster(dev, offs, flat, sc, tile_size, None, True)
+    bg = torch.rand(2, D, generator=torch.Generator().manual_seed(5)).to(gpu) if D in (20, 64) else None
+    cpu, out_r, alpha_r, amb = _oracle_raster(dev, offs, flat, sc, tile_size, bg, True)
     g = torch.Generator().manual_seed(17)
     keep = (~amb)[..., None].float()
     vc, va = torch.randn(out_r.shape, generator=g) * keep, torch.randn(alpha_r.shape, generator=g) * keep
     (out_r * vc.double()).sum().add((alpha_r * va.double()).sum()).backward()
     leaves = {k: v.clone().requires_grad_(k != "colors") for k, v in dev.items()}
     out, alpha = rd.rasterize_to_pixels(leaves["means2d"], leaves["conics"], leaves["colors"], leaves["opacities"],
-                                        sc.width, sc.height, tile_size, offs, flat, absgrad=True)
+                                        sc.width, sc.height, tile_size, offs, flat, backgrounds=bg, absgrad=True)
     ((out * vc.to(gpu)).sum() + (alpha * va.to(gpu)).sum()).backward()
     assert leaves["colors"].grad is None
     for k in ("opacities", "conics", "means2d"):
