@@ -20,8 +20,9 @@ only = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 t0 = time.time()
 near = ties = 0
 for case in range(cases):
-    n = rng.choice([1, 7, 64, 300, 900])
-    w, h = rng.choice([(16, 16), (33, 17), (70, 45), (128, 96), (200, 120)])
+    big = os.environ.get("FUZZ_LARGE") == "1"   # fewer, larger cases (several seconds of oracle time each)
+    n = rng.choice([300, 900, 3000] if big else [1, 7, 64, 300, 900])
+    w, h = rng.choice([(200, 120), (320, 200), (400, 300)] if big else [(16, 16), (33, 17), (70, 45), (128, 96), (200, 120)])
     views = rng.choice([1, 1, 2, 3])
     ts = rng.choice([8, 16])
     F = rng.choice([0, 0, 5, 16, 29, 32, 61, 64, 93])
