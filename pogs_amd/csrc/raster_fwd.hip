@@ -183,7 +183,10 @@ __global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
     float *__restrict__ render_colors, float *__restrict__ render_alphas, int32_t *__restrict__ last_ids) {
   constexpr int GS = 16;                 // Gaussians per matrix product
   using Rg = Region<16, PPL>;
-  constexpr int ROW = color_row(CD), CDP = round4(CD), BS = batch_size(PPL);
+  constexpr int ROW = color_row(CD), CDP = round4(CD);
+  // staged entries per batch: a full wavefront's worth at 2 pixels per lane (11-14 KB of LDS still leave the three
+  // wavefronts per SIMD the registers allow; half as many staging round trips: 0.451 -> 0.436 ms), 32 otherwise
+  constexpr int BS = PPL == 2 ? WAVE : batch_size(PPL);
   constexpr int CM = 32 * NM;            // channels on the matrix cores
   constexpr int CV = CDP - CM, CV2 = CV / 2;  // channels on the vector ALU
   static_assert(CD >= CM && CV >= 0 && CV <= 16, "pass width");
