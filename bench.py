@@ -2,13 +2,17 @@
 """Headline benchmark: Mpix/s of one rasterization forward+backward at the POGS training-step shape
 (1M Gaussians, 1920x1080, SH-RGB + expected depth + 32 feature channels) on MI355X.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W [--config cfg2|cfg1|cfg5|cfg3]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one `rasterization()` call forward + backward (projection, SH, binning + sort, compositing and
-every backward kernel) on one camera per GPU with inputs resident in HBM; with N > 1 every rank renders a
-different view of the same (replicated) scene and the flat parameter-gradient buffer is mean-all-reduced
-over RCCL inside the step (weak scaling: per-GPU work fixed).  Rank 0 prints ONE JSON line.
+every backward kernel) on one camera per GPU with inputs resident in HBM.  Every step renders another camera of a
+ring around the scene, as the reference's trainer draws another camera each iteration.  With N > 1 every rank
+renders a different view of the same (replicated) scene and the parameter gradients are exchanged over RCCL
+inside the step (weak scaling: per-GPU work fixed).  Rank 0 prints ONE JSON line.
+
+`--config` selects another of the workload shapes (cfg1 plumbing shape, cfg5 4K stress shape, cfg3 the tracker's
+50-iteration pose loop); the default, cfg2, is the headline.
 """
 from __future__ import annotations
 
@@ -26,15 +30,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from pogs_amd import rendering  # noqa: E402
-from pogs_amd.dist import GradExchange  # noqa: E402
+from pogs_amd import _lib, rendering  # noqa: E402
+from pogs_amd.dist import make_exchange  # noqa: E402
 from pogs_amd.scenes import make_scene  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E nominal
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E nominal
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+
+CONFIGS = {
+    # name: (gaussians, width, height, feature channels, tile size)
+    "cfg1": (10_000, 256, 256, 16, 16),
+    "cfg2": (1_000_000, 1920, 1080, 32, 16),
+    "cfg5": (6_000_000, 3840, 2160, 64, 16),
+}
 
 
 def stage_bytes(N, C, I, P, K, F, D, key_bits):
-    """Algorithmic bytes per entry point for one forward+backward call; they sum to
+    """Algorithmic bytes per entry point for one forward+backward call over I (Gaussian, tile) pairs; they sum to
     N(212+36K+8F) + I(108+24s+12D) + P(8D+20) with s = ceil(key_bits/8) radix passes."""
     s = math.ceil(key_bits / 8)
     cn = C * N
@@ -44,7 +56,7 @@ def stage_bytes(N, C, I, P, K, F, D, key_bits):
         "pr_isect_count": 0,
         # the two-level sort is priced as the reference's one sort: its bytes are charged to the second level
         "pr_depth_order": 0,
-        "pr_isect_emit_sort": I * (12 + 24 * s) + I * 8,   # incl. the offsets table (formerly pr_isect_offsets)
+        "pr_isect_emit_sort": I * (12 + 24 * s) + I * 8,   # incl. the offsets table
         "pr_raster_fwd": I * (28 + 4 * D) + P * (4 * D + 8),
         "pr_raster_bwd": I * (28 + 4 * D) + I * (32 + 4 * D) + P * (4 * D + 12),
         "pr_project_bwd": cn * (28 + 44 + 44),
@@ -106,10 +118,65 @@ def cpu_baseline(sc, F, tile_size, target_s=25.0):
     t_total = t_rast + t_front * frac
     return {
         "value": pixels / t_total / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
-        "sample": (f"1M-Gaussian 1080p scene: projection+SH+binning of all Gaussians in PyTorch CPU "
+        "sample": (f"{sc.n}-Gaussian {W}x{H} scene, view 0: projection+SH+binning of all Gaussians in PyTorch CPU "
                    f"({t_front:.1f} s per frame, charged pro rata), C/OpenMP compositing fwd+bwd of every "
                    f"{stride}th tile, {reps} pass(es) ({n_tiles} tiles = {frac:.2f} frames, {t_rast:.1f} s), D={D}; "
                    f"projection/SH backward not included"),
+    }
+
+
+def copy_peak_gbs(dev):
+    """Measured HBM peak beside the nominal one: a 1 GiB device-to-device copy (read + write)."""
+    a_buf = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    b_buf = torch.empty_like(a_buf)
+    for _ in range(2):
+        b_buf.copy_(a_buf)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b_buf.copy_(a_buf)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * a_buf.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def pmc_record(workload_key):
+    """Per-launch HBM bytes of the entry points from this build's counter runs (profiles/pmc_traffic.json, written
+    by scripts/pmc_summary.py), when they were taken on this workload."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(pmc))
+    except Exception:
+        return {}
+    return rec if rec.get("workload") == workload_key else {}
+
+
+def tracking_config(args, dev):
+    """cfg3: the tracker's per-frame pose optimisation (pogs/tracking/rigid_group_optimizer.py:402-453), 50
+    iterations per frame on 200k Gaussians at 640x360.  Single GPU in the reference: replicas only."""
+    from pogs_amd.tracking import TrackingLoop
+
+    loop = TrackingLoop.synthetic(dev, n=200_000, width=640, height=360, groups=4, seed=0)
+    iters = 50
+    for _ in range(max(args.warmup, 1)):
+        loop.frame(iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = None
+    for _ in range(args.steps):
+        losses = loop.frame(iters)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    return {
+        "metric": "ms/frame tracking (200k Gauss, 640x360, 50 iters)", "value": ms, "unit": "ms/frame", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False,
+        "scaling": "replicas only", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "tracking loop: per iteration rigid-group transform, RGB+ED render at tile 8, 64-channel "
+                               "feature render at tile 16 + channel MLP, L2 losses, backward to [G,7] pose deltas, Adam",
+                   "gaussians": 200_000, "width": 640, "height": 360, "iterations_per_frame": iters, "groups": 4,
+                   "loss_first_to_last": [losses[0], losses[-1]]},
+        "roofline": None, "cpu_baseline": None,
     }
 
 
@@ -118,14 +185,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--features", type=int, default=32)
-    ap.add_argument("--tile-size", type=int, default=16)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS) + ["cfg3"])
+    ap.add_argument("--gaussians", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--features", type=int, default=None)
+    ap.add_argument("--tile-size", type=int, default=None)
+    ap.add_argument("--views", type=int, default=8, help="cameras on the ring the steps cycle through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra timed passes (other kernel variants)")
     ap.add_argument("--two-call", action="store_true",
                     help="render RGB+ED and the features as two gsplat-signature calls instead of one fused call")
+    ap.add_argument("--exchange", default="sharded", choices=["sharded", "allreduce"],
+                    help="N > 1: reduce-scatter + all-gather of the gradients in overlapped buckets, or one mean "
+                         "all-reduce per large gradient after the backward pass")
     args = ap.parse_args()
 
     if os.environ.get("POGS_BENCH_HANG_DUMP"):   # debugging aid: dump every thread's stack after N seconds
@@ -143,6 +216,11 @@ def main():
         raise SystemExit(f"LOCAL_RANK {local_rank} but only {n_dev} device(s)")
     dev = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(dev)
+    if args.config == "cfg3":
+        if world != 1:
+            raise SystemExit("cfg3 (tracking) is single-GPU in the reference: run replicas, not ranks")
+        print(json.dumps(tracking_config(args, dev)), flush=True)
+        return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("POGS_BENCH_BACKEND", "nccl")   # "gloo" for a rehearsal on a shared GPU
@@ -151,34 +229,42 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    N, W, H, F, ts = args.gaussians, args.width, args.height, args.features, args.tile_size
-    sc = make_scene(N, W, H, n_features=F, n_views=max(world, 1), seed=0)
-    view = rank % sc.viewmats.shape[0]
+    N, W, H, F, ts = CONFIGS[args.config]
+    N, W, H = args.gaussians or N, args.width or W, args.height or H
+    F, ts = (F if args.features is None else args.features), args.tile_size or ts
+    n_views = max(world, args.views, 1)
+    sc = make_scene(N, W, H, n_features=F, n_views=n_views, seed=0)
     params = {
         "means": sc.means, "quats": sc.quats, "log_scales": sc.log_scales, "opacity_logits": sc.opacity_logits,
         "sh": sc.sh, "features": sc.features,
     }
     params = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in params.items()}
-    viewmat = sc.viewmats[view:view + 1].to(dev).contiguous()
-    K = sc.Ks[view:view + 1].to(dev).contiguous()
-    # Multi-GPU: every .grad aliases one flat buffer that is mean-all-reduced each step.  Single GPU: plain
+    viewmats = sc.viewmats.to(dev).contiguous()
+    Ks = sc.Ks.to(dev).contiguous()
+    # Multi-GPU: the gradients are exchanged every step (mean over ranks).  Single GPU: plain
     # zero_grad(set_to_none=True) semantics, as the reference's trainer does between iterations.
-    grads = GradExchange(params.values()) if world > 1 else None
+    grads = make_exchange(args.exchange, params) if world > 1 else None
     D = 3 + F + 1
     g = torch.Generator().manual_seed(100 + rank)
     v_colors = torch.randn(1, H, W, D, generator=g).to(dev)
     v_alpha = torch.randn(1, H, W, 1, generator=g).to(dev)
-    info = {}
+    info = {"n_walked": [], "counter": 0}
 
-    def step():
+    def step(two_call=args.two_call):
+        i = info["counter"]
+        info["counter"] = i + 1
+        view = (rank + i) % n_views
+        viewmat, K = viewmats[view:view + 1], Ks[view:view + 1]
         for p in params.values():   # autograd adopts the gradient tensors the kernels produce
             p.grad = None
+        if grads is not None:
+            grads.begin_step()
         scales = torch.exp(params["log_scales"])
         opac = torch.sigmoid(params["opacity_logits"])
         common = dict(means=params["means"], quats=params["quats"], scales=scales, opacities=opac, viewmats=viewmat,
                       Ks=K, width=W, height=H, tile_size=ts, packed=False, near_plane=0.01, far_plane=1e10,
                       sparse_grad=False, rasterize_mode="classic")
-        if args.two_call:
+        if two_call:
             r1, a1, meta = rendering.rasterization(colors=params["sh"], sh_degree=3, render_mode="RGB+ED",
                                                    absgrad=True, **common)
             r2, a2, _ = rendering.rasterization(colors=params["features"], sh_degree=None, render_mode="RGB",
@@ -190,12 +276,21 @@ def main():
                                                  absgrad=True, features=params["features"], **common)
             torch.autograd.backward([r, a], [v_colors, v_alpha])
         info["meta"] = meta
-        info["tile_bits"] = (meta["tile_width"] * meta["tile_height"]).bit_length()
-        if world > 1:
-            grads.all_reduce_mean()
+        info["n_walked"].append(meta["n_composited_isects"])
+        if grads is not None:
+            grads.finish_step()
+
+    def timed(n_steps, **kw):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step(**kw)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n_steps
 
     for _ in range(args.warmup):
         step()
+    info["n_walked"].clear()
     timer = rendering.StageTimer()
     rendering.set_stage_timer(timer)
     if world > 1:
@@ -218,13 +313,15 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         pixels = world * H * W
         value = pixels / (elapsed / args.steps) / 1e6
-        # The algorithmic byte count is priced on the workload's intersection count under gsplat's binning rule
-        # (every tile under the 3-sigma box) -- read here, after the timed region, from the lazily built
-        # reference tables; the compositor itself walks the shorter footprint-tested lists.
-        I = info["meta"]["flatten_ids"].numel()
-        I_walked = info["meta"]["n_composited_isects"]
-        key_bits = 32 + info["tile_bits"]
-        per_stage, total_bytes = stage_bytes(N, 1, I, H * W, 16, F, D, key_bits)
+        n_tiles = math.ceil(W / ts) * math.ceil(H / ts)
+        walked = info["n_walked"]
+        I_walked = sum(walked) / len(walked)          # pairs the compositor's lists hold, mean over the timed views
+        # gsplat's binning rule (every tile under the 3-sigma box) for the last view -- read here, after the timed
+        # region, from the lazily built reference tables; the compositor walks the shorter footprint-tested lists.
+        I_gsplat = info["meta"]["flatten_ids"].numel()
+        key_bits = 32 + n_tiles.bit_length()
+        per_stage, total_bytes = stage_bytes(N, 1, I_walked, H * W, 16, F, D, key_bits)
+        per_stage_gsplat, total_gsplat = stage_bytes(N, 1, I_gsplat, H * W, 16, F, D, key_bits)
         summ = timer.summary()
         stages = {k: v[1] / max(v[0], 1) * (v[0] / args.steps) for k, v in summ.items()}  # ms per step
         dom = max((k for k in stages if per_stage.get(k, 0) > 0), key=stages.get)
@@ -232,50 +329,78 @@ def main():
         avg_ms = total_ms / launches
         dom_bytes = per_stage[dom] / (launches / args.steps)
         achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("workload") == f"{N}x{W}x{H}xF{F}ts{ts}":
-                    traffic = rec.get(dom)
-            except Exception:
-                traffic = None
-        # measured HBM peak beside the nominal one: a 1 GiB device-to-device copy (read + write)
-        a_buf = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-        b_buf = torch.empty_like(a_buf)
-        for _ in range(2):
-            b_buf.copy_(a_buf)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            b_buf.copy_(a_buf)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 5 * 2 * a_buf.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del a_buf, b_buf
+        pmc = pmc_record(f"{N}x{W}x{H}xF{F}ts{ts}")
+        # secondary line: FP32 work of the dominant kernel.  Per (pixel, Gaussian) pair the backward compositor does
+        # two channel contractions of D fused multiply-adds each plus ~30 for alpha, transmittance and the geometry
+        # gradients; the forward one contraction plus ~12.  A wavefront evaluates every pixel of its tile for every
+        # pair it walks, so pairs = walked (Gaussian, tile) pairs x tile area.
+        fma_per_pair = {"pr_raster_bwd": 2 * D + 30, "pr_raster_fwd": D + 12}.get(dom)
+        fp32 = None
+        if fma_per_pair:
+            flops = 2.0 * fma_per_pair * I_walked * ts * ts
+            fp32 = {"fma_per_pixel_pair": fma_per_pair, "pixel_pairs": I_walked * ts * ts,
+                    "achieved_tflops": flops / (avg_ms * 1e-3) / 1e12, "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
+                    "frac": flops / (avg_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                    "note": "upper bound on issued work: pairs behind a saturated pixel and half tiles a Gaussian "
+                            "does not reach are skipped"}
+        fwd_plan = _lib.raster_plan(D, ts, n_tiles)
+        bwd_plan = _lib.raster_plan(D, ts, n_tiles, backward=True)
         out = {
             "metric": "Mpix/s fwd+bwd (1M Gauss, 1080p, RGB+32ch feat)", "value": value, "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if not fwd_plan[2] else "f32 (forward colour accumulation split-bf16 x3 on matrix cores)",
+            "data": "synthetic",
             "config": {
-                "workload": ("POGS training step shape: %d Gaussians, %dx%d, SH-RGB(deg 3)+ED+%d feature channels, "
-                             "fwd+bwd, absgrad, tile %d, 1 view per GPU%s" % (
-                                 N, W, H, F, ts, ", fused single call" if not args.two_call else ", two calls")),
-                "gaussians": N, "width": W, "height": H, "channels": D, "n_isects": I, "n_isects_composited": I_walked,
-                "parallelism": "camera-sharded dp%d, in-place gradient mean all-reduce (%.0f MB: SH, features, packed rest)" % (
-                    world, (grads.nbytes() if grads is not None else 0) / 1e6) if world > 1 else "single GPU",
+                "workload": ("%s: POGS training step shape, %d Gaussians, %dx%d, SH-RGB(deg 3)+ED+%d feature channels, "
+                             "fwd+bwd, absgrad, tile %d, 1 view per GPU per step cycling over %d ring cameras%s" % (
+                                 args.config, N, W, H, F, ts, n_views,
+                                 ", fused single call" if not args.two_call else ", two calls")),
+                "gaussians": N, "width": W, "height": H, "channels": D,
+                "n_isects_composited": I_walked, "n_isects_composited_per_view": walked[:n_views],
+                "n_isects_gsplat_rule_last_view": I_gsplat,
+                "kernels": {"fwd": {"pixels_per_lane": fwd_plan[0], "channels_per_pass": fwd_plan[1],
+                                    "matrix_cores": fwd_plan[2]},
+                            "bwd": {"pixels_per_lane": bwd_plan[0], "channels_per_pass": bwd_plan[1],
+                                    "matrix_cores": bwd_plan[2]}},
+                "parallelism": ("camera-sharded dp%d, %s" % (world, grads.describe())) if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "measured_copy_peak_GBps": copy_gbs,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(dom),
+                "limited_by": "VALU issue (see fp32): the kernel moves well under what HBM could deliver",
+                "measured_copy_peak_GBps": copy_peak_gbs(dev),
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_launch_gsplat_rule": per_stage_gsplat[dom] / (launches / args.steps),
+                "fp32": fp32,
                 "whole_call": {"algorithmic_bytes": total_bytes, "achieved": total_bytes / (ms_per_step * 1e-3) / 1e9,
-                               "frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                               "frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "algorithmic_bytes_gsplat_rule": total_gsplat},
             },
             "stages_ms_per_step": {k: round(v, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])},
         }
+        if world == 1 and not args.no_variants:
+            # the same step with other choices, each timed over the same number of steps after two warm-ups
+            variants = {}
+
+            def variant(name, note, **kw):
+                for _ in range(2):
+                    step(**kw)
+                sec = timed(args.steps, **kw)
+                variants[name] = {"Mpix/s": H * W / sec / 1e6, "ms_per_step": sec * 1e3, "what": note}
+
+            cur = int(os.environ.get("POGS_RAST_FWD_MFMA", "0") or 0)
+            _lib.set_tuning(POGS_RAST_FWD_MFMA=0 if cur else 1)
+            variant("fwd_strict_f32" if cur else "fwd_split_bf16",
+                    "forward colour accumulation in float32 on the vector ALU (gsplat's arithmetic)" if cur else
+                    "forward colour accumulation as three bf16 matrix products (error ~1.2e-5 * max|colour|), opt-in")
+            _lib.set_tuning(POGS_RAST_FWD_MFMA=cur if cur else None)
+            variant("two_call", "unmodified-POGS call pattern: RGB+ED and the features as two rasterization() calls "
+                                "(pogs/pogs.py:352,493)", two_call=not args.two_call)
+            rendering.set_count_speculation(False)
+            variant("no_count_speculation", "every call waits on the host for its intersection count, as gsplat does")
+            rendering.set_count_speculation(True)
+            out["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, F, ts)
         else:

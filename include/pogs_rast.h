@@ -41,6 +41,11 @@ const char *pr_error_string(int code);
 const char *pr_last_hip_error(void);
 /* Largest channel count pr_raster_fwd / pr_raster_bwd accept in one call. */
 int pr_max_channels(void);
+/* Kernel-variant overrides (environment variables POGS_RAST_FWD_PPL, POGS_RAST_FWD_CHUNK, POGS_RAST_FWD_MFMA,
+ * POGS_RAST_BWD_PPL, POGS_RAST_BWD_MFMA, POGS_MLP_VARIANT) are read once, at the first call that needs them;
+ * this re-reads them.  For tests and A/B measurements that switch variants inside one process; not to be called
+ * while another thread is inside the library.  No gsplat counterpart. */
+void pr_reload_tuning(void);
 
 /* ---- projection: stands in for gsplat `fully_fused_projection` forward (non-packed) --------------------
  * means[N,3] quats[N,4] (wxyz, unnormalised) scales[N,3] viewmats[C,4,4] (world->camera) Ks[C,3,3].
@@ -172,6 +177,16 @@ int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics
                   const float *v_render_alphas, int absgrad, int geom_grad, float *v_geom, float *v_colors,
                   const pr_color_segment *segments, const pr_grad_segment *v_segments, int n_segments,
                   void *stream);
+
+/* Which kernel variant pr_raster_fwd / pr_raster_bwd pick for a D-channel call over n_tiles_total = C*tile_h*tile_w
+ * tiles: pixels per lane (4: one wavefront per 16x16 tile, 2: two, 1: four; always 1 for 8x8 tiles), channels per
+ * pass (wider renders take ceil(D / channels_per_pass) passes), and whether the pass runs its channel contraction on
+ * the matrix cores.  Any out pointer may be NULL.  For tests, benchmarks and profiles that must name the kernel
+ * they exercised.  No gsplat counterpart. */
+int pr_raster_fwd_plan(int D, int tile_size, int64_t n_tiles_total, int *pixels_per_lane, int *channels_per_pass,
+                       int *matrix_cores);
+int pr_raster_bwd_plan(int D, int tile_size, int64_t n_tiles_total, int geom_grad, int color_grad,
+                       int *pixels_per_lane, int *channels_per_pass, int *matrix_cores);
 
 /* ---- rigid-group transform of the Gaussian model (the tracker's per-iteration pose update) ----
  * Replaces the Warp kernel apply_to_model (pogs/tracking/utils.py:53-93, launched at

@@ -21,6 +21,7 @@ SIGNATURES = {
     "pr_error_string": (c_char_p, [c_int]),
     "pr_last_hip_error": (c_char_p, []),
     "pr_max_channels": (c_int, []),
+    "pr_reload_tuning": (None, []),
     "pr_project_fwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float, c_float, c_float,
                                _P, _P, _P, _P, _P, _P]),
     "pr_project_bwd": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P, c_int, _P, _P, c_int,
@@ -39,6 +40,8 @@ SIGNATURES = {
                               c_int64, c_int, _P, _P, _P, _P, c_int, _P]),
     "pr_raster_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                               c_int64, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+    "pr_raster_fwd_plan": (c_int, [c_int, c_int, c_int64, _P, _P, _P]),
+    "pr_raster_bwd_plan": (c_int, [c_int, c_int, c_int64, c_int, c_int, _P, _P, _P]),
     "pr_mlp_mask_words": (c_size_t, [c_int64]),
     "pr_mlp_fwd": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "pr_mlp_bwd_input": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
@@ -112,3 +115,30 @@ def check(rc: int, what: str) -> None:
         if rc == -4:
             msg += ": " + lib.pr_last_hip_error().decode()
         raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+
+def raster_plan(D: int, tile_size: int, n_tiles_total: int, backward: bool = False, geom_grad: bool = True,
+                color_grad: bool = True):
+    """(pixels per lane, channels per pass, matrix cores?) of the compositor kernel the library picks."""
+    ppl, per, mm = c_int(0), c_int(0), c_int(0)
+    lib = load()
+    if backward:
+        rc = lib.pr_raster_bwd_plan(D, tile_size, n_tiles_total, int(geom_grad), int(color_grad),
+                                    ctypes.addressof(ppl), ctypes.addressof(per), ctypes.addressof(mm))
+    else:
+        rc = lib.pr_raster_fwd_plan(D, tile_size, n_tiles_total, ctypes.addressof(ppl), ctypes.addressof(per),
+                                    ctypes.addressof(mm))
+    check(rc, "pr_raster_plan")
+    return ppl.value, per.value, bool(mm.value)
+
+
+def set_tuning(**overrides) -> None:
+    """Set kernel-variant overrides for this process: ``set_tuning(POGS_RAST_BWD_PPL=4)`` puts the value in the
+    environment (``None`` removes it) and has the library re-read its tuning variables, which it otherwise reads
+    only once.  For tests and A/B scripts; the render path never calls this."""
+    for k, v in overrides.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    load().pr_reload_tuning()

@@ -30,6 +30,20 @@ inline int check_launch(const char *where) {
 
 constexpr int WAVE = 64;
 
+// Tuning aids (POGS_RAST_* / POGS_MLP_VARIANT environment variables): read ONCE, when the library first needs
+// them, never on the call path.  pr_reload_tuning() re-reads the environment (tests and A/B scripts that switch
+// kernel variants inside one process call it after changing a variable).  Fields are plain ints written before
+// any reader exists or under the caller's own serialisation of pr_reload_tuning against render calls.
+struct Tuning {
+  int fwd_ppl;      // POGS_RAST_FWD_PPL: force 1/2/4 pixels per lane in the forward compositor (0 = planner)
+  int fwd_chunk;    // POGS_RAST_FWD_CHUNK: widest forward channel pass (0 = planner)
+  int fwd_mfma;     // POGS_RAST_FWD_MFMA: 1 = split-bf16 matrix-core colour accumulation for 32..72-channel passes
+  int bwd_ppl;      // POGS_RAST_BWD_PPL: as fwd_ppl for the backward compositor
+  int bwd_mfma;     // POGS_RAST_BWD_MFMA: 0 = vector kernels only for the geometry-only backward
+  int mlp_variant;  // POGS_MLP_VARIANT: -1 = default
+};
+const Tuning &tuning();
+
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // DPP helpers: v + (v moved across lanes by `ctrl`), lanes without a source add 0.

@@ -339,7 +339,7 @@ struct Variant {
   int pt, wpe, block;
   bool hoist, bf16;
 };
-// POGS_MLP_VARIANT selects a kernel shape and arithmetic (read per call, for measurements and tests):
+// POGS_MLP_VARIANT selects a kernel shape and arithmetic (read once, see Tuning in common.h; for measurements and tests):
 // 0-3 exact float32 (v_mfma_f32_32x32x2_f32), 4-6 split bf16 (3 x v_mfma_f32_32x32x16_bf16 per product).
 constexpr int N_VARIANTS = 7, DEFAULT_VARIANT = 4;
 Variant variant() {
@@ -348,8 +348,7 @@ Variant variant() {
                                             {2, 2, 256, false, false}, {2, 1, 256, true, false},
                                             {1, 4, 512, false, true},  {2, 2, 256, false, true},
                                             {1, 2, 256, false, true}};
-  const char *e = getenv("POGS_MLP_VARIANT");
-  const int v = e && *e ? atoi(e) : DEFAULT_VARIANT;
+  const int v = tuning().mlp_variant;
   return table[v >= 0 && v < N_VARIANTS ? v : DEFAULT_VARIANT];
 }
 

@@ -53,16 +53,12 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
   // 1 pixel per lane: 16-entry batches keep the slice (colours + reduction area) under 10 KB = 4 wavefronts/SIMD
   constexpr int BS = PPL == 1 ? 16 : batch_size(PPL);
   __shared__ WaveLds<CD, true, BS> lds[WPB];
-  const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  // Without an explicit order, blocks that share an XCD take a contiguous range of tiles (neighbouring
-  // tiles share Gaussians -> one L2).  With one, slot s processes tile tile_order[s]: the caller lists the
-  // tiles heaviest first so the last waves of the launch are the cheapest ones.
-  const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-  const int region = (int)bid * WPB + wave;
-  if (region >= n_regions) return;
-  WaveLds<CD, true, BS> &L = lds[wave];
-
-  const int tile_flat = tile_order ? tile_order[region / Rg::WPT] : region / Rg::WPT, sub = region % Rg::WPT;
+  static_assert(WPB == 1, "one wavefront per workgroup");
+  const int lane = threadIdx.x & 63;
+  const RegionId rid = region_of<Rg::WPT>(tile_order, n_regions);
+  if (!rid.valid) return;
+  WaveLds<CD, true, BS> &L = lds[0];
+  const int tile_flat = rid.tile_flat, sub = rid.sub;
   const int n_tiles = tile_w * tile_h;
   const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
   const int ty = tile / tile_w, tx = tile % tile_w;
@@ -362,7 +358,7 @@ static int launch_bwd(int C, int N, int D, int ch_off, const float *means2d, con
                       int ed_channel, const float *v_render_colors, const float *v_render_alphas, int absgrad,
                       float *v_geom, const GradSegs &gs, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
-  const unsigned grid = (unsigned)((n_regions + WPB - 1) / WPB);
+  const unsigned grid = region_grid(n_regions, Region<TS, PPL>::WPT, tile_order != nullptr);
   hipLaunchKernelGGL((raster_bwd_kernel<TS, PPL, CD, GEOM, CGRAD>), dim3(grid), dim3(64 * WPB), 0, stream, (int)n_regions, N, D,
                      ch_off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h,
                      isect_offsets, tile_order, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel,
@@ -397,10 +393,9 @@ __global__ void __launch_bounds__(64) raster_bwd_geom_mfma_kernel(
   __shared__ WaveLds<CD, false, BS> L;
   __shared__ float red[2 * 68];
   const int lane = threadIdx.x & 63;
-  const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-  const int region = (int)bid;
-  if (region >= n_regions) return;
-  const int tile_flat = tile_order ? tile_order[region / Rg::WPT] : region / Rg::WPT, sub = region % Rg::WPT;
+  const RegionId rid = region_of<Rg::WPT>(tile_order, n_regions);
+  if (!rid.valid) return;
+  const int tile_flat = rid.tile_flat, sub = rid.sub;
   const int n_tiles = tile_w * tile_h;
   const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
   const int ty = tile / tile_w, tx = tile % tile_w;
@@ -579,7 +574,8 @@ static int launch_bwd_geom_mfma(int C, int N, int D, const float *means2d, const
                                 const float *v_render_colors, const float *v_render_alphas, int absgrad, float *v_geom,
                                 hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<16, 1>::WPT;
-  hipLaunchKernelGGL((raster_bwd_geom_mfma_kernel<CD>), dim3((unsigned)n_regions), dim3(64), 0, stream, (int)n_regions,
+  const unsigned grid = region_grid(n_regions, Region<16, 1>::WPT, tile_order != nullptr);
+  hipLaunchKernelGGL((raster_bwd_geom_mfma_kernel<CD>), dim3(grid), dim3(64), 0, stream, (int)n_regions,
                      N, D, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
                      tile_order, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel,
                      v_render_colors, v_render_alphas, absgrad, v_geom);
@@ -602,11 +598,6 @@ static int pick_chunk(int want) {
   for (int c : kChunks)
     if (c >= want) return c;
   return -1;
-}
-
-static int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
 }
 
 struct BwdPlan {
@@ -632,7 +623,7 @@ static BwdPlan plan_bwd(int D, int geom_grad, bool color_grad, int tile_size, in
   // wavefronts per SIMD: measured 0.74 ms against 0.81 ms at 36 channels, 1M Gaussians, 1080p
   if (!color_grad && p.ppl == 4) p.ppl = 2;
   while (p.ppl > 1 && n_tiles_total * (4 / p.ppl) < 3072) p.ppl >>= 1;
-  const int forced = env_int("POGS_RAST_BWD_PPL", 0);
+  const int forced = tuning().bwd_ppl;
   if (forced == 1 || (forced == 2 && cd <= 72) || (forced == 4 && cd <= 36)) p.ppl = forced;
   return p;
 }
@@ -642,6 +633,21 @@ static BwdPlan plan_bwd(int D, int geom_grad, bool color_grad, int tile_size, in
 using namespace pr;
 
 extern "C" int pr_max_channels(void) { return 100; }
+
+extern "C" int pr_raster_bwd_plan(int D, int tile_size, int64_t n_tiles_total, int geom_grad, int color_grad,
+                                  int *pixels_per_lane, int *channels_per_pass, int *matrix_cores) {
+  if (D <= 0 || D > pr_max_channels() || (tile_size != 16 && tile_size != 8) || n_tiles_total < 0) return PR_EINVAL;
+  if (!geom_grad && !color_grad) return PR_EINVAL;
+  const BwdPlan plan = plan_bwd(D, geom_grad, color_grad != 0, tile_size, n_tiles_total);
+  if (pixels_per_lane) *pixels_per_lane = plan.ppl;
+  if (channels_per_pass) *channels_per_pass = plan.per;
+  if (matrix_cores) {
+    const int cd = pick_chunk(D);
+    *matrix_cores = geom_grad && !color_grad && tile_size == 16 && plan.ppl == 1 && tuning().bwd_mfma != 0 &&
+                    cd >= 16 && cd <= 72;
+  }
+  return PR_OK;
+}
 
 #define BWD_ARGS                                                                                                     \
   C, N, D, off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,           \
@@ -687,7 +693,7 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
   if ((int64_t)C * tile_w * tile_h * 4 > 2147483647ll) return PR_EUNSUPPORTED;
   const BwdPlan plan = plan_bwd(D, geom_grad, any_color_grad, tile_size, (int64_t)C * tile_w * tile_h);
   // geometry gradients only, 16x16 tiles at 1 pixel per lane: the dot products go to the matrix cores
-  if (geom_grad && !any_color_grad && tile_size == 16 && plan.ppl == 1 && env_int("POGS_RAST_BWD_MFMA", 1) != 0) {
+  if (geom_grad && !any_color_grad && tile_size == 16 && plan.ppl == 1 && tuning().bwd_mfma != 0) {
     const int cd = pick_chunk(D);
 #define GEOM_MFMA_ARGS                                                                                             \
   C, N, D, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets, tile_order, \

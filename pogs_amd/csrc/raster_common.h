@@ -59,6 +59,40 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nb) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// Which region a workgroup (= one wavefront) processes.  Without an explicit tile order, blocks that share an
+// XCD take a contiguous range of regions (neighbouring tiles share Gaussians -> one L2).  With one, launch slot
+// s processes tile tile_order[s] -- the caller lists the tiles heaviest first so that the last wavefronts of the
+// launch are the cheapest ones -- and the WPT wavefronts that share a tile are blocks b, b + 8, ..: the same XCD
+// under round-robin dispatch, a few blocks apart in time, so the tile's records and colour rows leave HBM once
+// and the other wavefronts' gathers hit that XCD's L2 (placement is for speed only; nothing depends on it).
+struct RegionId {
+  int tile_flat, sub;
+  bool valid;
+};
+template <int WPT>
+__device__ __forceinline__ RegionId region_of(const int32_t *__restrict__ tile_order, int n_regions) {
+  RegionId r;
+  if (tile_order) {
+    const unsigned b = blockIdx.x, x = b & 7u, i = b >> 3;
+    const int slot = (int)((i / WPT) * 8u + x);
+    r.sub = (int)(i % WPT);
+    r.valid = slot < n_regions / WPT;
+    r.tile_flat = r.valid ? tile_order[slot] : 0;
+  } else {
+    const int region = (int)xcd_remap(blockIdx.x, gridDim.x);
+    r.valid = region < n_regions;
+    r.tile_flat = region / WPT;
+    r.sub = region % WPT;
+  }
+  return r;
+}
+// Grid size that goes with region_of: with a tile order the tile slots are dealt to the 8 XCDs in whole groups.
+inline unsigned region_grid(int64_t n_regions, int wpt, bool ordered) {
+  if (!ordered) return (unsigned)n_regions;
+  const int64_t n_tiles = n_regions / wpt;
+  return (unsigned)((n_tiles + 7) / 8 * 8 * wpt);
+}
+
 // Wavefronts per workgroup.  One: a workgroup's LDS and wave slots are only handed to the next workgroup
 // when ALL of its waves have finished, so with tiles of unequal length multi-wave workgroups leave slots
 // idle behind their slowest tile; nothing here needs a workgroup (no barrier, LDS slices are per wave).

@@ -17,16 +17,12 @@ __global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
   constexpr int CDP = round4(CD);
   constexpr int BS = batch_size(PPL);
   __shared__ WaveLds<CD, false, BS> lds[WPB];
-  const int wave = WPB == 1 ? 0 : (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  // Without an explicit order, blocks that share an XCD take a contiguous range of tiles (neighbouring
-  // tiles share Gaussians -> one L2).  With one, slot s processes tile tile_order[s]: the caller lists the
-  // tiles heaviest first so the last waves of the launch are the cheapest ones.
-  const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-  const int region = (int)bid * WPB + wave;
-  if (region >= n_regions) return;
-  WaveLds<CD, false, BS> &L = lds[wave];
-
-  const int tile_flat = tile_order ? tile_order[region / Rg::WPT] : region / Rg::WPT, sub = region % Rg::WPT;
+  static_assert(WPB == 1, "one wavefront per workgroup");
+  const int lane = threadIdx.x & 63;
+  const RegionId rid = region_of<Rg::WPT>(tile_order, n_regions);
+  if (!rid.valid) return;
+  WaveLds<CD, false, BS> &L = lds[0];
+  const int tile_flat = rid.tile_flat, sub = rid.sub;
   const int n_tiles = tile_w * tile_h;
   const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
   const int ty = tile / tile_w, tx = tile % tile_w;
@@ -192,11 +188,9 @@ __global__ void __launch_bounds__(64) raster_fwd_mfma_kernel(
   static_assert(CD >= CM && CV >= 0 && CV <= 16, "pass width");
   __shared__ WaveLds<CD, false, BS> L;
   const int lane = threadIdx.x & 63;
-  const unsigned bid = tile_order ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-  const int region = (int)bid;
-  if (region >= n_regions) return;
-
-  const int tile_flat = tile_order ? tile_order[region / Rg::WPT] : region / Rg::WPT, sub = region % Rg::WPT;
+  const RegionId rid = region_of<Rg::WPT>(tile_order, n_regions);
+  if (!rid.valid) return;
+  const int tile_flat = rid.tile_flat, sub = rid.sub;
   const int n_tiles = tile_w * tile_h;
   const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
   const int ty = tile / tile_w, tx = tile % tile_w;
@@ -422,7 +416,8 @@ static int launch_fwd_mfma(int C, int N, int D, int ch_off, const float *means2d
                            const int32_t *flatten_ids, int64_t n_isects, int ed_channel, float *render_colors,
                            float *render_alphas, int32_t *last_ids, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<16, PPL>::WPT;
-  hipLaunchKernelGGL((raster_fwd_mfma_kernel<PPL, CD, NM>), dim3((unsigned)n_regions), dim3(64), 0, stream, (int)n_regions, N, D,
+  const unsigned grid = region_grid(n_regions, Region<16, PPL>::WPT, tile_order != nullptr);
+  hipLaunchKernelGGL((raster_fwd_mfma_kernel<PPL, CD, NM>), dim3(grid), dim3(64), 0, stream, (int)n_regions, N, D,
                      ch_off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
                      tile_order, flatten_ids, (int)n_isects, ed_channel, render_colors, render_alphas, last_ids);
   return check_launch("raster_fwd_mfma_kernel");
@@ -435,7 +430,7 @@ static int launch_fwd(int C, int N, int D, int ch_off, const float *means2d, con
                       int64_t n_isects, int ed_channel,
                       float *render_colors, float *render_alphas, int32_t *last_ids, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
-  const unsigned grid = (unsigned)((n_regions + WPB - 1) / WPB);
+  const unsigned grid = region_grid(n_regions, Region<TS, PPL>::WPT, tile_order != nullptr);
   hipLaunchKernelGGL((raster_fwd_kernel<TS, PPL, CD>), dim3(grid), dim3(64 * WPB), 0, stream, (int)n_regions, N, D, ch_off,
                      means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
                      tile_order, flatten_ids, (int)n_isects, ed_channel, render_colors, render_alphas, last_ids);
@@ -454,11 +449,6 @@ static int pick_chunk(int want) {
   return -1;
 }
 
-static int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-
 struct FwdPlan {
   int ppl, per;
 };
@@ -470,7 +460,7 @@ static FwdPlan plan_fwd(int D, int tile_size, int64_t n_tiles_total) {
   // per chunk, which is cheaper than losing the per-Gaussian amortisation).  Small images take all channels
   // in one pass with fewer pixels per lane, which also doubles or quadruples the number of wavefronts.
   const bool many_tiles = tile_size == 16 && n_tiles_total >= 3072;
-  int max_chunk = env_int("POGS_RAST_FWD_CHUNK", many_tiles ? 48 : 100);
+  const int max_chunk = tuning().fwd_chunk > 0 ? tuning().fwd_chunk : many_tiles ? 48 : 100;
   const int n_chunks = (D + max_chunk - 1) / max_chunk;
   p.per = ((D + n_chunks - 1) / n_chunks + 3) & ~3;
   if (tile_size == 8) {
@@ -484,7 +474,7 @@ static FwdPlan plan_fwd(int D, int tile_size, int64_t n_tiles_total) {
   // vector instruction every four cycles, the SIMD takes one every two): 0.52 vs 0.57 ms at 36 channels.
   p.ppl = cd <= 24 ? 4 : cd <= 72 ? 2 : 1;
   while (p.ppl > 1 && n_tiles_total * (4 / p.ppl) < 3072) p.ppl >>= 1;
-  const int forced = env_int("POGS_RAST_FWD_PPL", 0);
+  const int forced = tuning().fwd_ppl;
   if (forced == 1 || (forced == 2 && cd <= 72) || (forced == 4 && cd <= 48)) p.ppl = forced;
   return p;
 }
@@ -492,6 +482,19 @@ static FwdPlan plan_fwd(int D, int tile_size, int64_t n_tiles_total) {
 }  // namespace pr
 
 using namespace pr;
+
+extern "C" int pr_raster_fwd_plan(int D, int tile_size, int64_t n_tiles_total, int *pixels_per_lane,
+                                  int *channels_per_pass, int *matrix_cores) {
+  if (D <= 0 || D > pr_max_channels() || (tile_size != 16 && tile_size != 8) || n_tiles_total < 0) return PR_EINVAL;
+  const FwdPlan plan = plan_fwd(D, tile_size, n_tiles_total);
+  const int cd = pick_chunk(min(plan.per, D));
+  if (pixels_per_lane) *pixels_per_lane = plan.ppl;
+  if (channels_per_pass) *channels_per_pass = plan.per;
+  if (matrix_cores)
+    *matrix_cores = tuning().fwd_mfma != 0 && tile_size == 16 && cd >= 32 &&
+                    ((plan.ppl == 2 && cd <= 48) || (plan.ppl == 1 && cd <= 72));
+  return PR_OK;
+}
 
 #define FWD_ARGS                                                                                                    \
   C, N, D, off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,          \
@@ -521,7 +524,9 @@ extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const fl
   int rcs = make_color_segs(colors, D, segments, n_segments, n_isects > 0, cs);
   if (rcs) return rcs;
   const FwdPlan plan = plan_fwd(D, tile_size, (int64_t)C * tile_w * tile_h);
-  const bool use_mfma = env_int("POGS_RAST_FWD_MFMA", 1) != 0;  // 0: vector-ALU kernels only (for A/B runs)
+  // Float32 accumulation (what gsplat's kernel does) unless the caller opts into the split-bf16 matrix-core
+  // variant, whose error grows with the colour magnitude (about 1.2e-5 * max|colour|).
+  const bool use_mfma = tuning().fwd_mfma != 0;
   for (int off = 0; off < D; off += plan.per) {
     const int cd = pick_chunk(min(plan.per, D - off));
     int rc = PR_EUNSUPPORTED;

@@ -156,3 +156,28 @@ def sharded_step(render_view, n_views: int, grads: FlatGrads, rank: int, world: 
     elif n_views > 1:
         grads.flat.div_(float(n_views))
     return {"views": float(len(mine))}
+
+
+class _AllReduceExchange:
+    """``GradExchange`` behind the step interface ``bench.py`` drives: nothing before the backward pass, the mean
+    all-reduce of every gradient after it."""
+
+    def __init__(self, params: Dict[str, Tensor], group=None):
+        self.ex = GradExchange(params.values())
+        self.group = group
+
+    def begin_step(self) -> None:
+        pass
+
+    def finish_step(self) -> None:
+        self.ex.all_reduce_mean(self.group)
+
+    def describe(self) -> str:
+        return "in-place gradient mean all-reduce after the backward pass (%.0f MB: SH, features, packed rest)" % (
+            self.ex.nbytes() / 1e6)
+
+
+def make_exchange(kind: str, params: Dict[str, Tensor], group=None):
+    if kind == "allreduce":
+        return _AllReduceExchange(params, group)
+    raise ValueError(kind)

@@ -14,7 +14,8 @@ costs one projection, one binning and one walk over the tile lists instead of tw
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Tuple
+import threading
+from typing import Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -187,20 +188,79 @@ class _SphericalHarmonics(torch.autograd.Function):
 
 
 _ORDER_MIN_TILES = 2048  # fewer tiles than wave slots: nothing to balance
-_count_history: Dict[tuple, tuple] = {}   # binning configuration -> intersection counts of the last two calls
-_pinned: Dict[int, Tensor] = {}
-
-
-def _pinned_count(dev: torch.device) -> Tensor:
-    """One page-locked int64 per device for the asynchronous read-back of the intersection count."""
-    t = _pinned.get(dev.index)
-    if t is None:
-        t = _pinned[dev.index] = torch.empty(1, dtype=torch.int64, pin_memory=True)
-    return t
-
-
-_side_streams: Dict[int, "torch.cuda.Stream"] = {}
 _ASYNC_DEPTH_ORDER_MIN = 100_000
+
+
+class _CallState:
+    """What survives from one ``rasterization`` call to the next, shared by every thread and stream that renders:
+    recent intersection counts per binning configuration (to size the lists without waiting for the count), a
+    pool of page-locked words for the asynchronous read-back of the count, and the second stream of each (device,
+    caller stream) pair.  Every access goes through one lock; a buffer or stream handed out belongs to the call
+    that took it until it is given back, so calls in flight on different threads or streams (a viewer thread next
+    to the trainer, autograd's backward thread re-rendering) share nothing mutable."""
+
+    HISTORY = 8           # counts remembered per configuration
+    STABLE = 0.02         # spread below which the tight margin applies
+    LOOSE = 0.25          # spread up to which a guess is still made (cycling cameras)
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.history: Dict[tuple, List[int]] = {}
+        self.pinned: Dict[int, List[Tensor]] = {}
+        self.side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
+        self.speculate = True
+
+    def guess(self, key) -> Optional[int]:
+        """Capacity to size the lists with, or None when the host should wait for the exact count."""
+        with self.lock:
+            h = self.history.get(key)
+            if not self.speculate or h is None or len(h) < 2 or min(h) <= 0:
+                return None
+            hi, lo = max(h), min(h)
+            if hi - lo <= self.STABLE * hi:
+                return int(hi * 1.03) + 1024
+            if hi - lo <= self.LOOSE * hi:
+                return int(hi * 1.10) + 1024
+            return None
+
+    def record(self, key, n_isects: int, missed: bool) -> None:
+        with self.lock:
+            if missed:                       # a guess was too small: no speculation until two more exact counts
+                self.history[key] = [n_isects]
+                return
+            h = self.history.setdefault(key, [])
+            h.append(n_isects)
+            del h[:-self.HISTORY]
+
+    def take_pinned(self, dev: torch.device) -> Tensor:
+        with self.lock:
+            pool = self.pinned.setdefault(dev.index, [])
+            if pool:
+                return pool.pop()
+        return torch.empty(1, dtype=torch.int64, pin_memory=True)
+
+    def give_pinned(self, dev: torch.device, t: Tensor) -> None:
+        with self.lock:
+            self.pinned.setdefault(dev.index, []).append(t)
+
+    def side_stream(self, dev: torch.device, main: "torch.cuda.Stream") -> "torch.cuda.Stream":
+        key = (dev.index, main.cuda_stream)
+        with self.lock:
+            s = self.side_streams.get(key)
+        if s is None:
+            s = torch.cuda.Stream(dev)
+            with self.lock:
+                s = self.side_streams.setdefault(key, s)
+        return s
+
+
+_state = _CallState()
+
+
+def set_count_speculation(on: bool) -> None:
+    """Switch the sizing of the intersection lists from earlier counts on or off (off: every call waits for its
+    exact count on the host, as gsplat does)."""
+    _state.speculate = bool(on)
 
 
 def _depth_order_async(depths: Tensor):
@@ -211,9 +271,7 @@ def _depth_order_async(depths: Tensor):
     dev = depths.device
     C, N = depths.shape
     main = torch.cuda.current_stream(dev)
-    side = _side_streams.get(dev.index)
-    if side is None:
-        side = _side_streams[dev.index] = torch.cuda.Stream(dev)
+    side = _state.side_stream(dev, main)
     depths = depths.detach().contiguous()
     side.wait_stream(main)
     with torch.cuda.stream(side):
@@ -279,34 +337,31 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
             return ids, flat
 
         # The intersection count sizes the lists.  Waiting for it on the host leaves the GPU idle for the
-        # round trip, so when the same configuration has produced a stable count on the previous calls
-        # (a tracking loop, repeated views) the lists are sized from that count plus a margin, the kernels
-        # read the true count from device memory, and the host compares afterwards -- by then the GPU has
-        # the sort queued.  A guess that turns out too small costs one repeated call and switches the
-        # speculation off until the count is stable again.
+        # round trip, so when the same configuration has produced similar counts on the previous calls
+        # (a tracking loop, repeated or cycling views) the lists are sized from the largest of them plus a
+        # margin, the kernels read the true count from device memory, and the host compares afterwards -- by
+        # then the GPU has the sort queued.  A guess that turns out too small costs one repeated call and
+        # switches the speculation off until the counts are settled again.
         key = (dev.index, C, N, tile_size, tile_width, tile_height, conics is not None)
-        hist = _count_history.get(key)
-        guess = None
-        if hist is not None and hist[0] > 0 and abs(hist[1] - hist[0]) <= 0.02 * hist[0]:
-            guess = int(max(hist) * 1.03) + 1024
+        guess = _state.guess(key)
         if guess is None:
             n_isects = int(cum[-1].item())
             isect_ids, flatten_ids = emit(n_isects, False)
         else:
-            host = _pinned_count(dev)
+            host = _state.take_pinned(dev)
             host.copy_(cum[-1:], non_blocking=True)
             done = torch.cuda.Event()
             done.record()
             isect_ids, flatten_ids = emit(guess, True)
             done.synchronize()
             n_isects = int(host.item())
+            _state.give_pinned(dev, host)
             if n_isects > guess:
                 isect_ids, flatten_ids = emit(n_isects, False)
             else:
                 flatten_ids = flatten_ids[:n_isects]
                 isect_ids = None if isect_ids is None else isect_ids[:n_isects]
-        missed = guess is not None and n_isects > guess
-        _count_history[key] = (0, n_isects) if hist is None or missed else (hist[1], n_isects)
+        _state.record(key, n_isects, guess is not None and n_isects > guess)
     if want_order:
         return tiles_per_gauss, isect_ids, flatten_ids, offsets, order
     return tiles_per_gauss, isect_ids, flatten_ids, offsets

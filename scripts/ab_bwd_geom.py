@@ -2,7 +2,7 @@
 Usage: python scripts/ab_bwd_geom.py D   (prints NaN counts and max differences of the three geometry gradients)"""
 import os, sys, math, torch
 sys.path.insert(0, ".")
-from pogs_amd import rendering as rd
+from pogs_amd import rendering as rd, _lib
 from tests._util import small_scene, scene_args
 gpu = torch.device("cuda:0")
 sc = small_scene(n=600, w=70, h=45, views=2, seed=8, lo=0.02, hi=0.3)
@@ -18,7 +18,7 @@ opac = a["opacities"][None].expand(2, -1).contiguous()
 vc = torch.randn(2, sc.height, sc.width, D, generator=g).to(gpu)
 res = {}
 for mode in ("0", "1"):
-    os.environ["POGS_RAST_BWD_MFMA"] = mode
+    _lib.set_tuning(POGS_RAST_BWD_MFMA=mode)
     m = means2d.detach().clone().requires_grad_(True); c = conics.detach().clone().requires_grad_(True); o = opac.clone().requires_grad_(True)
     out, al = rd.rasterize_to_pixels(m, c, colors, o, sc.width, sc.height, 16, offs, flat, absgrad=True)
     ((out * vc).sum() + al.sum()).backward()

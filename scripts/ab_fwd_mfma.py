@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from pogs_amd import rendering  # noqa: E402
+from pogs_amd import _lib, rendering  # noqa: E402
 from pogs_amd.scenes import make_scene  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -26,7 +26,7 @@ def render():
 
 res = {}
 for mode in ("0", "1"):
-    os.environ["POGS_RAST_FWD_MFMA"] = mode
+    _lib.set_tuning(POGS_RAST_FWD_MFMA=mode)
     for _ in range(3):
         r, a, meta = render()
     t = rendering.StageTimer()

@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from pogs_amd import rendering  # noqa: E402
+from pogs_amd import _lib, rendering  # noqa: E402
 from pogs_amd.scenes import make_scene  # noqa: E402
 
 dev = torch.device("cuda:0")
@@ -31,7 +31,7 @@ for name, env in (("vector 4 px/lane", {"POGS_RAST_BWD_PPL": "4", "POGS_RAST_BWD
                   ("vector 2 px/lane", {"POGS_RAST_BWD_PPL": "2", "POGS_RAST_BWD_MFMA": "0"}),
                   ("vector 1 px/lane", {"POGS_RAST_BWD_PPL": "1", "POGS_RAST_BWD_MFMA": "0"}),
                   ("matrix 1 px/lane", {"POGS_RAST_BWD_PPL": "1", "POGS_RAST_BWD_MFMA": "1"})):
-    os.environ.update(env)
+    _lib.set_tuning(**env)
     for _ in range(3):
         step()
     t = rendering.StageTimer()

@@ -19,3 +19,23 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+_TUNING_VARS = ("POGS_RAST_FWD_PPL", "POGS_RAST_FWD_CHUNK", "POGS_RAST_FWD_MFMA", "POGS_RAST_BWD_PPL",
+                "POGS_RAST_BWD_MFMA", "POGS_MLP_VARIANT")
+
+
+@pytest.fixture
+def tuning():
+    """``tuning(POGS_RAST_BWD_PPL=4, ...)`` forces kernel variants for one test: the library reads these variables
+    once, so the fixture sets them, has the library re-read them, and restores both afterwards."""
+    from pogs_amd import _lib
+
+    saved = {k: os.environ.get(k) for k in _TUNING_VARS}
+
+    def apply(**overrides):
+        assert set(overrides) <= set(_TUNING_VARS), overrides
+        _lib.set_tuning(**overrides)
+
+    yield apply
+    _lib.set_tuning(**saved)

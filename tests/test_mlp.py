@@ -18,9 +18,9 @@ ARITH = {"f32": ("1", 2e-5), "bf16x3": ("4", 1e-4)}
 
 
 @pytest.fixture(params=sorted(ARITH))
-def arith(request, monkeypatch):
+def arith(request, tuning):
     variant, tol = ARITH[request.param]
-    monkeypatch.setenv("POGS_MLP_VARIANT", variant)
+    tuning(POGS_MLP_VARIANT=variant)
     return tol
 
 
