@@ -152,6 +152,15 @@ def pmc_record(workload_key):
     return rec if rec.get("workload") == workload_key else {}
 
 
+def pair_counts(workload_key):
+    """Iteration counts of the backward compositor from the diagnostic build (profiles/r02_bwd_pair_counts.json)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_bwd_pair_counts.json")))
+    except Exception:
+        return None
+    return rec if rec.get("workload") == workload_key else None
+
+
 def tracking_config(args, dev):
     """cfg3: the tracker's per-frame pose optimisation (pogs/tracking/rigid_group_optimizer.py:402-453), 50
     iterations per frame on 200k Gaussians at 640x360.  Single GPU in the reference: replicas only."""
@@ -257,8 +266,8 @@ def main():
         viewmat, K = viewmats[view:view + 1], Ks[view:view + 1]
         for p in params.values():   # autograd adopts the gradient tensors the kernels produce
             p.grad = None
-        if grads is not None:
-            grads.begin_step()
+        if grads is not None:   # the forward waits for each parameter of the previous exchange where it first reads it
+            grads.begin_step(wait=["means", "quats", "log_scales", "opacity_logits"])
         scales = torch.exp(params["log_scales"])
         opac = torch.sigmoid(params["opacity_logits"])
         common = dict(means=params["means"], quats=params["quats"], scales=scales, opacities=opac, viewmats=viewmat,
@@ -288,6 +297,9 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n_steps
 
+    for _ in range(n_views):    # set-up: one render per ring camera sizes the allocator's pools for every view
+        step()
+    info["counter"] = 0
     for _ in range(args.warmup):
         step()
     info["n_walked"].clear()
@@ -330,23 +342,30 @@ def main():
         dom_bytes = per_stage[dom] / (launches / args.steps)
         achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
         pmc = pmc_record(f"{N}x{W}x{H}xF{F}ts{ts}")
-        # secondary line: FP32 work of the dominant kernel.  Per (pixel, Gaussian) pair the backward compositor does
-        # two channel contractions of D fused multiply-adds each plus ~30 for alpha, transmittance and the geometry
-        # gradients; the forward one contraction plus ~12.  A wavefront evaluates every pixel of its tile for every
-        # pair it walks, so pairs = walked (Gaussian, tile) pairs x tile area.
-        fma_per_pair = {"pr_raster_bwd": 2 * D + 30, "pr_raster_fwd": D + 12}.get(dom)
+        # Secondary line: FP32 work of the dominant kernel.  Per (pixel, Gaussian) pair the backward compositor does two
+        # channel contractions of D fused multiply-adds each plus ~30 for alpha, transmittance and the geometry
+        # gradients.  Which pairs it evaluates is measured, not assumed: the diagnostic build (scripts/diag_bwd.py)
+        # counts the (tile, Gaussian) iterations that pass the kernel's "does any pixel take this Gaussian" test and
+        # how many of them run over half the tile only; every such iteration evaluates all pixels of the (half) tile.
         fp32 = None
-        if fma_per_pair:
-            flops = 2.0 * fma_per_pair * I_walked * ts * ts
-            fp32 = {"fma_per_pixel_pair": fma_per_pair, "pixel_pairs": I_walked * ts * ts,
+        diag = pair_counts(f"{N}x{W}x{H}xF{F}ts{ts}")
+        if dom == "pr_raster_bwd" and diag:
+            iters, half = diag["contributing_iters"], diag["half_tile_iters"]
+            pairs = (iters - half) * ts * ts + half * ts * ts / 2
+            fma = 2 * D + 30
+            flops = 2.0 * fma * pairs
+            fp32 = {"fma_per_pixel_pair": fma, "tile_gaussian_iterations": iters, "of_them_half_tile": half,
+                    "pixel_pairs_evaluated": pairs, "pixel_pairs_contributing": diag["active_px_per_iter"] * iters,
                     "achieved_tflops": flops / (avg_ms * 1e-3) / 1e12, "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
                     "frac": flops / (avg_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
-                    "note": "upper bound on issued work: pairs behind a saturated pixel and half tiles a Gaussian "
-                            "does not reach are skipped"}
+                    "source": "profiles/r02_bwd_pair_counts.json (diagnostic build, view 0)"}
         fwd_plan = _lib.raster_plan(D, ts, n_tiles)
         bwd_plan = _lib.raster_plan(D, ts, n_tiles, backward=True)
         out = {
-            "metric": "Mpix/s fwd+bwd (1M Gauss, 1080p, RGB+32ch feat)", "value": value, "unit": "Mpix/s",
+            "metric": ("Mpix/s fwd+bwd (1M Gauss, 1080p, RGB+32ch feat)" if args.config == "cfg2" and not (
+                args.gaussians or args.width or args.height or args.features is not None or args.tile_size)
+                else "Mpix/s fwd+bwd (%s: %d Gauss, %dx%d, RGB+ED+%dch feat)" % (args.config, N, W, H, F)),
+            "value": value, "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if not fwd_plan[2] else "f32 (forward colour accumulation split-bf16 x3 on matrix cores)",

@@ -11,7 +11,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpogs_rast.so")
+# POGS_RAST_LIB names another build of the same library (e.g. the cycle-stamp diagnostic build, EXTRA=-DPR_DIAG=2)
+LIB_PATH = os.environ.get("POGS_RAST_LIB") or os.path.join(_HERE, "lib", "libpogs_rast.so")
 
 _P = c_void_p
 

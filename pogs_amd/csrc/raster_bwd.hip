@@ -222,6 +222,8 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
           atomicAdd(&g_diag[1], (unsigned long long)npx);
           atomicAdd(&g_diag[2], (unsigned long long)nslots);
           atomicAdd(&g_diag[5], (unsigned long long)__builtin_popcountll(any));
+          if (PPL == 4 && HALF_SKIP && ((slot[2 % PPL] | slot[3 % PPL]) == 0ull || (slot[0] | slot[1 % PPL]) == 0ull))
+            atomicAdd(&g_diag[3], 1ull);   // iterations composited over half the tile only
         }
       }
 #endif

@@ -21,6 +21,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
+from .dist import pending, wait_ready
 
 
 def _ptr(t: Optional[Tensor]):
@@ -662,6 +663,10 @@ def rasterization(
     _check_device(means, quats, scales, opacities, colors, viewmats, Ks, backgrounds, features)
     width, height = int(width), int(height)
 
+    # Parameters whose multi-GPU exchange of the previous step is still in flight (pogs_amd.dist.ShardedExchange)
+    # are waited for on the device, each right before the first kernel that reads it.
+    for t in (means, quats, scales, opacities, viewmats, Ks, backgrounds):
+        wait_ready(t)
     radii, means2d, depths, conics, compensations = fully_fused_projection(
         means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
         calc_compensations=(rasterize_mode == "antialiased"))
@@ -675,25 +680,24 @@ def rasterization(
         assert features.dim() == 2 and features.shape[0] == N, features.shape
     with_depth = render_mode in ("RGB+D", "RGB+ED", "D", "ED")
     depth_only = render_mode in ("D", "ED")
-    campos = None
-    if sh_degree is not None and not depth_only:
-        if colors.dim() == 4:
-            if C != 1:
-                raise NotImplementedError("per-camera SH coefficients with C > 1")
-            colors = colors[0]
-        campos = camera_centers(viewmats)
-    # channels = [rgb or given colours | features | depth]: the compositor gathers from the tensors in place
-    parts = []
-    if not depth_only:
-        if sh_degree is not None:
-            parts.append(_SphericalHarmonics.apply(int(sh_degree), means, campos, colors, radii, True))
-        else:
-            parts.append(colors)            # [C,N,D], or [N,D] shared by all cameras
-        if features is not None:
-            parts.append(features)          # [N,F], shared
-    if with_depth:
-        parts.append(depths[..., None])     # [C,N,1]
-    n_channels = sum(p.shape[-1] for p in parts)
+    use_sh = sh_degree is not None and not depth_only
+    if use_sh and colors.dim() == 4:
+        if C != 1:
+            raise NotImplementedError("per-camera SH coefficients with C > 1")
+        colors = colors[0]
+
+    def evaluate_colours():
+        wait_ready(colors)
+        if use_sh:
+            return _SphericalHarmonics.apply(int(sh_degree), means, camera_centers(viewmats), colors, radii, True)
+        return colors                       # [C,N,D], or [N,D] shared by all cameras
+
+    # The view-dependent colours normally run next to the depth sort; coefficients still on the links are
+    # evaluated after the binning instead, which needs the geometry only.
+    late_colours = pending(colors)
+    rgb = None if depth_only or late_colours else evaluate_colours()
+    n_channels = ((0 if depth_only else (3 if use_sh else colors.shape[-1]) + (features.shape[-1] if features is not None else 0))
+                  + (1 if with_depth else 0))
     bgs = backgrounds
     if bgs is not None:
         if depth_only:
@@ -709,6 +713,17 @@ def rasterization(
     _, _, flatten_ids, isect_offsets, tile_order = _bin_tiles(
         means2d, radii, depths, tile_size, tile_width, tile_height, False, True, True, conics=conics,
         opacities=opac, depth_order=depth_order)
+
+    # channels = [rgb or given colours | features | depth]: the compositor gathers from the tensors in place
+    parts = []
+    if not depth_only:
+        parts.append(evaluate_colours() if late_colours else rgb)
+        if features is not None:
+            wait_ready(features)
+            parts.append(features)          # [N,F], shared
+    if with_depth:
+        parts.append(depths[..., None])     # [C,N,1]
+    assert n_channels == sum(p.shape[-1] for p in parts)
 
     # expected depth (ED): the depth channel is divided by max(alpha, 1e-10) inside the kernels
     ed_channel = n_channels - 1 if render_mode in ("ED", "RGB+ED") else -1

@@ -98,8 +98,18 @@ def test_gsplat_import_shim_resolves_to_this_package():
     import subprocess
     import sys
 
+    # exactly the names the reference imports: pogs/pogs.py:11-12, pogs/pogs_pipeline.py:29,
+    # nerfstudio/models/splatfacto.py:26,29
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r);"
             "from gsplat.rendering import rasterization; import pogs_amd.rendering as r;"
+            "from gsplat.strategy import DefaultStrategy; from gsplat.strategy import DefaultStrategy, MCMCStrategy;"
+            "import pogs_amd.strategy as st; assert DefaultStrategy is st.DefaultStrategy;"
+            "s = DefaultStrategy(prune_opa=0.1, grow_grad2d=0.0008, grow_scale3d=0.01, grow_scale2d=0.05,"
+            " prune_scale3d=0.5, prune_scale2d=0.15, refine_scale2d_stop_iter=0, refine_start_iter=500,"
+            " refine_stop_iter=15000, reset_every=3000, refine_every=100, pause_refine_after_reset=0, absgrad=True,"
+            " revised_opacity=False, verbose=True);"
+            "assert 'grad2d' in s.initialize_state(scene_scale=1.0);"
+            "\ntry:\n    MCMCStrategy()\n    raise SystemExit('MCMCStrategy must raise')\nexcept NotImplementedError:\n    pass\n"
             "from gsplat.cuda._torch_impl import _quat_to_rotmat; import torch;"
             "assert rasterization is r.rasterization;"
             "assert torch.allclose(_quat_to_rotmat(torch.tensor([1.,0,0,0])), torch.eye(3))"

@@ -1,0 +1,80 @@
+"""Size-independent properties at the full sizes of the secondary workload shapes (the oracle cannot finish these in
+seconds): the 4K stress shape (6M Gaussians, 3840x2160, RGB+ED + 64 feature channels = 68 composited channels,
+32,400 tiles -> 15 tile bits) forward + backward, and the tracker's 50-iteration pose loop at 200k Gaussians,
+640x360.  ``bench.py --config cfg5`` / ``--config cfg3`` time the same workloads."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stress_shape_properties_forward_and_backward(gpu):
+    from pogs_amd import _lib
+    from pogs_amd import rendering as rd
+    from pogs_amd.scenes import make_scene
+
+    N, W, H, F = 6_000_000, 3840, 2160, 64
+    D = 3 + F + 1
+    n_tiles = (W // 16) * (H // 16)
+    assert n_tiles == 32400 and n_tiles.bit_length() == 15
+    # the kernels this shape runs: forward in two passes of <= 36 channels, backward all 68 channels at once
+    assert _lib.raster_plan(D, 16, n_tiles)[:2] == (2, 36)
+    assert _lib.raster_plan(D, 16, n_tiles, backward=True)[:2] == (2, D)
+    sc = make_scene(N, W, H, n_features=F, seed=0)
+    dev = dict(means=sc.means, quats=sc.quats, scales=sc.log_scales.exp(), opacities=torch.sigmoid(sc.opacity_logits),
+               colors=sc.sh, viewmats=sc.viewmats, Ks=sc.Ks)
+    dev = {k: v.to(gpu).contiguous() for k, v in dev.items()}
+    feats = sc.features.to(gpu)
+    feats[:, 5] = 1.0                                   # a constant channel: renders to alpha
+    del sc
+    kw = dict(width=W, height=H, sh_degree=3, render_mode="RGB+ED", packed=False, absgrad=True)
+    f1 = feats.clone().requires_grad_(True)
+    means = dev["means"].clone().requires_grad_(True)
+    out, alpha, meta = rd.rasterization(**{**dev, "means": means}, features=f1, **kw)
+    assert out.shape == (1, H, W, D) and meta["tile_width"] * meta["tile_height"] == n_tiles
+    assert (out[..., 3 + 5:3 + 6] - alpha).abs().max().item() <= 2e-5          # sum of weights = alpha
+    assert 0.3 < alpha.mean().item() < 1.0 and bool(torch.isfinite(out).all())
+    # expected depth lies between the nearest and the farthest visible Gaussian wherever something was hit
+    d = out[..., -1][alpha[..., 0] > 1e-3]
+    vis_depth = meta["depths"][meta["radii"] > 0]
+    assert d.min().item() >= vis_depth.min().item() - 1e-3 and d.max().item() <= vis_depth.max().item() + 1e-3
+    # backward of the constant channel's sum: v_feature[g, 5] = sum over pixels of the weight of g, so their total is
+    # the total alpha; every other feature channel gets no gradient; the geometry gradients are finite
+    out[..., 3 + 5].sum().backward()
+    gsum, asum = f1.grad[:, 5].double().sum().item(), alpha.double().sum().item()
+    assert abs(gsum - asum) <= 1e-4 * asum, (gsum, asum)
+    assert f1.grad[:, :5].abs().max().item() == 0 and f1.grad[:, 6:].abs().max().item() == 0
+    assert bool((f1.grad[:, 5] >= 0).all()) and bool(torch.isfinite(means.grad).all())
+    ab = meta["means2d"].absgrad
+    assert ab is not None and bool(torch.isfinite(ab).all()) and bool((ab >= 0).all())
+    # rendering is linear in the colours (forward only, 2 a - 3 b)
+    with torch.no_grad():
+        fb = torch.randn(feats.shape, generator=torch.Generator().manual_seed(3)).to(gpu)
+        oa = out.detach()[..., 3:-1]
+        ob = rd.rasterization(**dev, features=fb, **kw)[0][..., 3:-1]
+        oc = rd.rasterization(**dev, features=2 * feats - 3 * fb, **kw)[0][..., 3:-1]
+        lin = (2 * oa - 3 * ob - oc).abs().max().item()
+    assert lin <= 1e-3, lin
+    del oa, ob, oc, fb, out
+    # gsplat's tables: sorted keys, 15 tile bits, offsets partition them
+    ids = meta["isect_ids"]
+    assert ids.numel() > N and bool((ids[1:] >= ids[:-1]).all())
+    assert int((ids >> 32).max()) < n_tiles and int(ids.max()) >> (32 + 15) == 0
+    offs = meta["isect_offsets"].flatten().long()
+    assert int(offs[0]) == 0 and bool((offs[1:] >= offs[:-1]).all())
+    assert int(meta["tiles_per_gauss"].sum()) == ids.numel()
+
+
+def test_tracking_loop_reduces_its_loss(gpu):
+    """cfg3: 200k Gaussians in 4 rigid groups at 640x360, observation rendered after the groups were moved; 50
+    iterations of the per-frame loop (rigid transform -> RGB+ED at tile 8 -> 64-channel features at tile 16 ->
+    channel MLP -> losses -> backward to the [4,7] pose deltas -> Adam) must bring the loss down."""
+    from pogs_amd.tracking import TrackingLoop
+
+    loop = TrackingLoop.synthetic(gpu, n=200_000, width=640, height=360, groups=4, seed=0)
+    losses = loop.frame(50)
+    assert len(losses) == 50 and all(l == l for l in losses)
+    assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
+    assert min(losses[25:]) <= min(losses[:25])
+    d = loop.part_deltas.detach()
+    assert bool(torch.isfinite(d).all()) and float((d[:, :3].abs().max())) < 0.2
