@@ -124,6 +124,15 @@ int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii,
 size_t pr_depth_order_scratch_bytes(int C, int N);
 int pr_depth_order(int C, int N, const float *depths, int32_t *depth_order, void *scratch, size_t scratch_bytes,
                    void *stream);
+/* pr_depth_order for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It has no counterpart in the reference (gsplat allocates its sort buffers through torch).
+ * Same result as pr_depth_order, but the kernels' scratch (sort keys, index sequence, the radix sort's temporary
+ * storage) lives in a 24 MiB device array inside the library instead of a caller-supplied buffer; the call
+ * allocates and frees nothing.  Limit: C*N <= pr_depth_order_static_max() (about 1.25 million on MI355X: the 1M-Gaussian training shape fits); larger inputs
+ * return PR_EUNSUPPORTED with the reason in pr_last_hip_error().  Every call on one GPU uses that GPU's one array:
+ * calls that overlap on one GPU (two streams, two threads) race -- serialise them or use pr_depth_order. */
+int64_t pr_depth_order_static_max(void);
+int pr_depth_order_static(int C, int N, const float *depths, int32_t *depth_order, void *stream);
 /* isect_offsets[C,tile_h,tile_w] int32: index of the first intersection of every (camera, tile). */
 int pr_isect_offsets(int64_t n_isects, const int64_t *isect_ids, int C, int tile_w, int tile_h,
                      int32_t *isect_offsets, void *stream);

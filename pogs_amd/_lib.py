@@ -36,6 +36,8 @@ SIGNATURES = {
                                    _P, _P, _P, _P, c_size_t, _P]),
     "pr_depth_order_scratch_bytes": (c_size_t, [c_int, c_int]),
     "pr_depth_order": (c_int, [c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "pr_depth_order_static_max": (c_int64, []),
+    "pr_depth_order_static": (c_int, [c_int, c_int, _P, _P, _P]),
     "pr_isect_offsets": (c_int, [c_int64, _P, c_int, c_int, c_int, _P, _P]),
     "pr_raster_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                               c_int64, c_int, _P, _P, _P, _P, c_int, _P]),
@@ -113,8 +115,9 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         lib = load()
         msg = lib.pr_error_string(rc).decode()
-        if rc == -4:
-            msg += ": " + lib.pr_last_hip_error().decode()
+        detail = lib.pr_last_hip_error().decode()
+        if rc == -4 or (rc == -2 and detail.startswith(what)):
+            msg += ": " + detail
         raise RuntimeError(f"{what} failed ({rc}): {msg}")
 
 

@@ -9,6 +9,8 @@ namespace pr {
 
 // Records the text of a failed HIP call for pr_last_hip_error().
 void set_hip_error(hipError_t e, const char *where);
+// Detail for a PR_EUNSUPPORTED / PR_EINVAL return, read through the same accessor (pr_last_hip_error).
+void set_error_text(const char *text);
 
 inline int check_launch(const char *where) {
   hipError_t e = hipGetLastError();

@@ -8,6 +8,8 @@
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace pr {
@@ -557,6 +559,64 @@ extern "C" int pr_depth_order(int C, int N, const float *depths, int32_t *depth_
   PR_HIP(rocprim::radix_sort_pairs<SortConfig>(temp, tb, (const uint32_t *)k_in, k_out, (const uint32_t *)v_in,
                                                (uint32_t *)depth_order, (size_t)total, 0u, 32u, st));
   return PR_OK;
+}
+
+// ---- the same depth order for callers that cannot allocate ---------------------------------------------------
+// pr_depth_order's kernels work in a caller-supplied scratch buffer (sort keys in and out, the index sequence, the
+// radix sort's own temporary storage).  This variant keeps that buffer in a file-scope device array instead, so a
+// caller under HIP graph capture, in a tight serving loop or in a harness that forbids allocation hands over
+// nothing but its input and its output.  Each GPU the library runs on holds the array until the process ends.
+namespace {
+constexpr size_t STATIC_SCRATCH_BYTES = (size_t)24 << 20;   // enough for C*N of about 1.25 million on MI355X (see the size check)
+constexpr int MAX_DEVICES = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+// In host code `scratch` is only a handle for the symbol; its device address differs per GPU and is looked up
+// once per device (with that device current) and used from then on wherever the memory is meant.
+static void *g_static_scratch[MAX_DEVICES];
+static std::mutex g_static_scratch_lock;
+
+static int static_scratch_ptr(void **out) {
+  int dev = -1;
+  PR_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEVICES) return PR_EUNSUPPORTED;
+  std::lock_guard<std::mutex> hold(g_static_scratch_lock);
+  if (!g_static_scratch[dev]) {
+    void *p = nullptr;
+    PR_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return PR_EHIP;
+    g_static_scratch[dev] = p;
+  }
+  *out = g_static_scratch[dev];
+  return PR_OK;
+}
+
+extern "C" int64_t pr_depth_order_static_max(void) {
+  // the largest C*N whose scratch (three 4-byte arrays + the sort's temporary storage) fits the static array
+  int64_t lo = 0, hi = (int64_t)1 << 24;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) / 2;
+    if (pr_depth_order_scratch_bytes(1, (int)mid) <= STATIC_SCRATCH_BYTES) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+extern "C" int pr_depth_order_static(int C, int N, const float *depths, int32_t *depth_order, void *stream) {
+  if (C < 0 || N < 0) return PR_EINVAL;
+  const int64_t total = (int64_t)C * N;
+  if (total == 0) return PR_OK;
+  if (!depths || !depth_order) return PR_EINVAL;
+  if (total > (int64_t)2147483647 || pr_depth_order_scratch_bytes(C, N) > STATIC_SCRATCH_BYTES) {
+    set_error_text("pr_depth_order_static: C*N exceeds the static scratch (pr_depth_order_static_max()); use "
+                   "pr_depth_order with a caller-supplied buffer");
+    return PR_EUNSUPPORTED;
+  }
+  void *ptr = nullptr;
+  const int rc = static_scratch_ptr(&ptr);
+  if (rc) return rc;
+  // every byte the kernels read from the buffer is written earlier in the same call (keys and indices by
+  // depth_keys_kernel, the sort's counters by its own initialisation), so nothing needs clearing between calls
+  return pr_depth_order(C, N, depths, depth_order, ptr, STATIC_SCRATCH_BYTES, stream);
 }
 
 extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii, const float *depths,

@@ -11,6 +11,7 @@ static thread_local char g_hip_error[512] = "";
 void set_hip_error(hipError_t e, const char *where) {
   snprintf(g_hip_error, sizeof(g_hip_error), "%s: %s", where, hipGetErrorString(e));
 }
+void set_error_text(const char *text) { snprintf(g_hip_error, sizeof(g_hip_error), "%s", text); }
 
 static Tuning g_tuning;
 static std::once_flag g_tuning_once;
