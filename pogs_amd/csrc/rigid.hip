@@ -92,7 +92,9 @@ rigid_bwd_kernel(int N, int G, const float *__restrict__ init_p2ws, const float 
   __syncthreads();
   int n = blockIdx.x * BLOCK + threadIdx.x;
   int g = n < N ? labels[n] : -1;
-  if (g >= 0 && g < G) {
+  float out[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool valid = g >= 0 && g < G;
+  if (valid) {
     Pose P = load_pose(init_p2ws, g), D = load_pose(p_deltas, g);
     V3 m = {means[3 * (size_t)n], means[3 * (size_t)n + 1], means[3 * (size_t)n + 2]};
     V3 gm = {v_means_out[3 * (size_t)n], v_means_out[3 * (size_t)n + 1], v_means_out[3 * (size_t)n + 2]};
@@ -118,13 +120,29 @@ rigid_bwd_kernel(int N, int G, const float *__restrict__ init_p2ws, const float 
     V3 pv = vec(P.q);
     float v_qd_w = vs_w * P.q.w + dot(vs_v, pv);
     V3 v_qd_v = pv * (-vs_w) + vs_v * P.q.w + cross(vs_v, pv);
-    float out[7] = {v_pd.x, v_pd.y, v_pd.z, v_qd_w, v_qd_v.x, v_qd_v.y, v_qd_v.z};
-    if (g < LDS_GROUPS) {
+    out[0] = v_pd.x, out[1] = v_pd.y, out[2] = v_pd.z, out[3] = v_qd_w;
+    out[4] = v_qd_v.x, out[5] = v_qd_v.y, out[6] = v_qd_v.z;
+  }
+  // Wavefront reduction before any atomic: the tracker has a handful of groups, so the 64 lanes of a wavefront
+  // would otherwise hit the same seven addresses.  One pass per group present in the wavefront (wave-uniform
+  // loop): lanes of that group contribute, the others add zeros, and one lane issues the seven adds.
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+  while (todo) {
+    const int leader = __builtin_ctzll(todo);
+    const int g0 = __builtin_amdgcn_readlane(g, leader);
+    const bool mine = valid && g == g0;
+    todo &= ~__builtin_amdgcn_ballot_w64(mine);
+    float tot[7];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) atomicAdd(&acc[g * 7 + k], out[k]);
-    } else {
+    for (int k = 0; k < 7; ++k) tot[k] = wave_sum_to_lane63(mine ? out[k] : 0.f);
+    if ((threadIdx.x & 63) == 63) {
+      if (g0 < LDS_GROUPS) {
 #pragma unroll
-      for (int k = 0; k < 7; ++k) atomic_add_noret(v_p_deltas + 7 * (size_t)g + k, out[k]);
+        for (int k = 0; k < 7; ++k) atomicAdd(&acc[g0 * 7 + k], tot[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomic_add_noret(v_p_deltas + 7 * (size_t)g0 + k, tot[k]);
+      }
     }
   }
   __syncthreads();

@@ -347,6 +347,12 @@ class ShardedExchange:
         works = []
         if W == 1:
             shard = flat[b.lo:b.hi]
+        elif self.direct and flat.is_cuda and self.backend == "gloo":
+            # rehearsal of the N > 1 path on a shared GPU without RCCL: gloo moves host memory only
+            h_send, h_recv = flat.cpu(), torch.empty(flat.shape, dtype=flat.dtype)
+            dist.all_to_all_single(h_recv, h_send, group=self.group)
+            recv = h_recv.to(flat.device)
+            shard = None
         elif self.direct:
             recv = torch.empty_like(flat)
             works.append(dist.all_to_all_single(recv, flat, group=self.group, async_op=True))
@@ -369,7 +375,11 @@ class ShardedExchange:
                     for name, lo, hi, at in b.segments()]
             self.update(segs)
             ag = []
-            if W > 1:
+            if W > 1 and cuda and self.backend == "gloo":       # rehearsal: through the host, blocking
+                h_full = torch.empty(b.total, dtype=b.flat_param.dtype)
+                dist.all_gather_into_tensor(h_full, b.flat_param[b.lo:b.hi].cpu(), group=self.group)
+                b.flat_param.copy_(h_full)
+            elif W > 1:
                 ag.append(dist.all_gather_into_tensor(b.flat_param, b.flat_param[b.lo:b.hi], group=self.group,
                                                       async_op=True))
             if cuda:

@@ -33,6 +33,11 @@ def scene_args(sc, dtype=torch.float32, device="cpu", requires_grad=False):
     return out
 
 
+# (name, worst |got - ref| / |ref| over the elements with |ref| > 1e-3 max|ref|, elements counted): what the
+# comparisons below measured beyond what they assert; tests/conftest.py writes it out at the end of a session.
+REL_ERRORS = []
+
+
 def assert_grad_close(got, ref, name, rtol=GRAD_RTOL, atol_frac=1e-4):
     if ref is None:  # the oracle's graph does not reach this input: the gradient is identically zero
         assert got is None or got.abs().max().item() == 0, name
@@ -45,6 +50,9 @@ def assert_grad_close(got, ref, name, rtol=GRAD_RTOL, atol_frac=1e-4):
         assert got.abs().max().item() == 0, name
         return
     err = (got - ref).abs()
+    big = ref.abs() > 1e-3 * scale
+    if big.any():
+        REL_ERRORS.append((name, float((err[big] / ref.abs()[big]).max()), int(big.sum())))
     bound = rtol * ref.abs() + atol_frac * scale
     bad = err > bound
     assert not bad.any(), (
