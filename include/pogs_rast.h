@@ -83,6 +83,13 @@ int pr_sh_bwd(int C, int N, int K, int degree, const float *means, const float *
               const float *coeffs, const int32_t *radii, int post, const float *v_colors, int ld_colors,
               float *v_coeffs, float *v_means, float *v_campos, void *stream);
 
+/* Camera centres in world coordinates, campos[C,3] = inverse(viewmats)[:, :3, 3], for rigid world->camera matrices
+ * (closed form -R^T t), and the cotangent of viewmats [C,4,4] (overwritten) as the derivative of the general matrix
+ * inverse gives it -- what gsplat's `rasterization` obtains from `torch.inverse(viewmats)` when it forms the SH view
+ * directions. */
+int pr_campos_fwd(int C, const float *viewmats, float *campos, void *stream);
+int pr_campos_bwd(int C, const float *viewmats, const float *v_campos, float *v_viewmats, void *stream);
+
 /* ---- tile binning: stands in for gsplat `isect_tiles` + `isect_offset_encode` --------------------------
  * Phase 1: tiles_per_gauss[C,N] int32 and its inclusive prefix sum cum_tiles[C*N] int64 (may be NULL with
  * scratch NULL: counts only).  The caller reads cum_tiles[C*N-1] back to the host to learn n_isects (the only

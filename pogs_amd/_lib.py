@@ -29,6 +29,8 @@ SIGNATURES = {
                                _P, _P, _P, _P, _P, _P]),
     "pr_sh_fwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P]),
     "pr_sh_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, _P]),
+    "pr_campos_fwd": (c_int, [c_int, _P, _P, _P]),
+    "pr_campos_bwd": (c_int, [c_int, _P, _P, _P, _P]),
     "pr_isect_count_scratch_bytes": (c_size_t, [c_int, c_int]),
     "pr_isect_count": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "pr_isect_sort_scratch_bytes": (c_size_t, [c_int, c_int, c_int64, c_int64]),

@@ -681,3 +681,56 @@ extern "C" int pr_sh_bwd(int C, int N, int K, int degree, const float *means, co
                        campos, coeffs, radii, post, v_colors, ld_colors, v_coeffs, v_means, v_campos);
   return check_launch("sh_bwd_kernel");
 }
+
+
+// ---- camera centres -------------------------------------------------------------------------------------------
+// c = inverse(V)[:3, 3] for rigid world->camera matrices V = [R t; 0 1]: c = -R^T t.  The backward is that of the
+// GENERAL matrix inverse, dM = -M dV M with M = inverse(V) = [R^T c; 0 1], so the gradient equals what autograd gives
+// for torch.inverse(viewmats)[:, :3, 3] (the expression gsplat's rasterization() differentiates):
+//   v_V[i][j] = -u[i] * M[j][3],  u[i] = sum_a M[a][i] v_c[a]  ->  u = (R v_c, <c, v_c>),  M[.][3] = (c, 1).
+namespace pr {
+namespace {
+__global__ void campos_fwd_kernel(int C, const float *__restrict__ viewmats, float *__restrict__ campos) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float *V = viewmats + 16 * (int64_t)c;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) campos[3 * c + j] = -(V[0 + j] * V[3] + V[4 + j] * V[7] + V[8 + j] * V[11]);
+}
+__global__ void campos_bwd_kernel(int C, const float *__restrict__ viewmats, const float *__restrict__ v_campos,
+                                  float *__restrict__ v_viewmats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float *V = viewmats + 16 * (int64_t)c;
+  const float g[3] = {v_campos[3 * c], v_campos[3 * c + 1], v_campos[3 * c + 2]};
+  float cc[4], u[4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) cc[j] = -(V[0 + j] * V[3] + V[4 + j] * V[7] + V[8 + j] * V[11]);
+  cc[3] = 1.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) u[i] = V[4 * i] * g[0] + V[4 * i + 1] * g[1] + V[4 * i + 2] * g[2];
+  u[3] = cc[0] * g[0] + cc[1] * g[1] + cc[2] * g[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v_viewmats[16 * (int64_t)c + 4 * i + j] = -u[i] * cc[j];
+}
+}  // namespace
+}  // namespace pr
+
+extern "C" int pr_campos_fwd(int C, const float *viewmats, float *campos, void *stream) {
+  if (C < 0) return PR_EINVAL;
+  if (C == 0) return PR_OK;
+  if (!viewmats || !campos) return PR_EINVAL;
+  hipLaunchKernelGGL(pr::campos_fwd_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, C, viewmats, campos);
+  return pr::check_launch("pr_campos_fwd");
+}
+
+extern "C" int pr_campos_bwd(int C, const float *viewmats, const float *v_campos, float *v_viewmats, void *stream) {
+  if (C < 0) return PR_EINVAL;
+  if (C == 0) return PR_OK;
+  if (!viewmats || !v_campos || !v_viewmats) return PR_EINVAL;
+  hipLaunchKernelGGL(pr::campos_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, C, viewmats,
+                     v_campos, v_viewmats);
+  return pr::check_launch("pr_campos_bwd");
+}

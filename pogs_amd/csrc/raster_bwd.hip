@@ -584,6 +584,321 @@ static int launch_bwd_geom_mfma(int C, int N, int D, const float *means2d, const
   return check_launch("raster_bwd_geom_mfma_kernel");
 }
 
+// ---- full backward (geometry + colour gradients) with BOTH channel contractions on the matrix cores ----------
+// 16x16 tiles, 1 pixel per lane (a 16x4 strip per wavefront), passes of 32..72 channels.  Per batch of 32 staged
+// Gaussians:
+//   (1) S[g][p] = <colour_g, v_p>: as in the geometry-only kernel above -- A = staged colour rows from LDS, B = v^T
+//       built once per tile from the lanes' own registers.
+//   (2) vC[g][c] = sum_p fac[p][g] * v[p][c] reduces over the PIXEL index, which lives on the lanes.  Its B operand
+//       v[p][c] (k = pixel, column = channel) is constant for the tile: transposed through LDS once, in the prologue,
+//       and kept as split-bf16 registers.  Its A operand fac^T[g][p] is produced by the back-to-front walk: every lane
+//       stores the bf16 head and residual of its pixel's fac into row g of a [32 slots][64 pixels] LDS image, which is
+//       read back row-wise (one 16-byte read per operand) after the walk.  The product replaces, per contributing
+//       (wavefront, Gaussian), the D packed FMAs, D/4 lane-swap folds and the per-Gaussian LDS read-back of the vector
+//       kernel.  Rows of slots that did not contribute hold stale data and are never written out (rows of a matrix
+//       product are independent).
+//   Result layout: lane = channel (l & 31), register r = slot (r&3) + 8(r>>2) + 4(l>>5): one float atomic instruction
+//   covers two 128-byte row segments, the shape global float atomics run at full rate for.
+// Channels past the last full 32 of the pass (the expected-depth channel among them) keep the vector path: fac * v is
+// folded with the geometry values.  Both contractions use hi.hi + lo.hi + hi.lo (about 16 mantissa bits per product);
+// gradients are held to 1e-3 relative, three orders above that.
+template <int CD>
+__global__ void __launch_bounds__(64) raster_bwd_full_mfma_kernel(
+    int n_regions, int N, int D, const float *__restrict__ means2d, const float *__restrict__ conics,
+    const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int width,
+    int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
+    const int32_t *__restrict__ tile_order, const int32_t *__restrict__ flatten_ids, int n_isects,
+    const float *__restrict__ render_alphas, const int32_t *__restrict__ last_ids,
+    const float *__restrict__ render_colors, int ed_channel, const float *__restrict__ v_render_colors,
+    const float *__restrict__ v_render_alphas, int absgrad, float *__restrict__ v_geom, const GradSegs gs) {
+  using Rg = Region<16, 1>;
+  constexpr int ROW = color_row(CD), CDP = round4(CD), BS = 32;
+  constexpr int KS = CDP / 16, CM = 16 * KS, CV = CDP - CM;  // S: k steps / channels on the matrix cores / on the VALU
+  constexpr int NT = CDP / 32, CC = 32 * NT, CR = CDP - CC;  // vC: 32-channel tiles / their channels / the rest
+  constexpr int NQR = CR / 4;                                // rest channels as quads in the reduction area
+  constexpr int FP = 72;                                     // fac image row pitch in 16-bit units: 64 pixels + pad
+  static_assert(KS >= 2 && NT >= 1 && CV < 16 && CR < 32 && CR % 4 == 0, "pass width");
+  __shared__ WaveLds<CD, false, BS> L;
+  __shared__ float red[(2 + NQR) * 68];
+  union FacImage {
+    struct {
+      unsigned short hi[BS * FP], lo[BS * FP];
+    } f;
+    float tr[64 * 33];  // prologue: v of the 64 pixels, one 32-channel block at a time, for the transpose
+  };
+  __shared__ __attribute__((aligned(16))) FacImage F;
+  static_assert(sizeof(F.f) >= sizeof(F.tr), "transpose area");
+  const int lane = threadIdx.x & 63;
+  const RegionId rid = region_of<Rg::WPT>(tile_order, n_regions);
+  if (!rid.valid) return;
+  const int tile_flat = rid.tile_flat, sub = rid.sub;
+  const int n_tiles = tile_w * tile_h;
+  const int cam = tile_flat / n_tiles, tile = tile_flat % n_tiles;
+  const int ty = tile / tile_w, tx = tile % tile_w;
+  const int x = tx * 16 + (lane % Rg::LX), y = ty * 16 + sub * Rg::RH + (lane / Rg::LX);
+  const int range_lo = isect_offsets[tile_flat];
+  const int nch = min(CD, D);
+  const float px0 = (float)x + 0.5f, py0 = (float)y + 0.5f;
+  const int mrow = lane & 31, mh = lane >> 5;
+
+  float T = 1.f, Bsum = 0.f, W = 0.f;
+  int last = range_lo;
+  unsigned b0h[KS][4], b1h[KS][4], b0l[KS][4], b1l[KS][4];  // v^T as B operand of S: pixels 0-31 / 32-63, head / residual
+  unsigned vbh[NT][4][4], vbl[NT][4][4];                    // v as B operand of vC: [channel tile][k step][register]
+  float vrest[CV > 0 ? CV : 1];                             // channels CM.. for S on the VALU
+  float crest[CR > 0 ? CR : 1];                             // channels CC.. for vC on the VALU
+  {
+    float v[CDP];
+#pragma unroll
+    for (int k = 0; k < CDP; ++k) v[k] = 0.f;
+    if (x < width && y < height) {
+      const int64_t pix = ((int64_t)cam * height + y) * width + x;
+      T = 1.f - render_alphas[pix];
+      last = last_ids[pix];
+      const float *src = v_render_colors + pix * D;
+      if ((D & 3) == 0) {
+#pragma unroll
+        for (int k = 0; k + 3 < CDP; k += 4)
+          if (k < nch) {
+            const float4 q = *reinterpret_cast<const float4 *>(src + k);
+            v[k] = q.x, v[k + 1] = q.y, v[k + 2] = q.z, v[k + 3] = q.w;
+          }
+      } else {
+#pragma unroll
+        for (int k = 0; k < CD; ++k)
+          if (k < nch) v[k] = src[k];
+      }
+      float w_ed = 0.f;
+      if (ed_channel >= 0) {  // expected depth out_d = X / max(a, 1e-10): see raster_bwd_kernel
+        const float a = 1.f - T, inv = 1.f / fmaxf(a, 1e-10f);
+#pragma unroll
+        for (int k = 0; k < CD; ++k)
+          if (k == ed_channel) {
+            if (a > 1e-10f) w_ed = -v[k] * render_colors[pix * D + ed_channel] * inv;
+            v[k] *= inv;
+          }
+      }
+      float w = v_render_alphas[pix] + w_ed;
+      if (backgrounds) {
+        const float *bg = backgrounds + (int64_t)cam * D;
+#pragma unroll
+        for (int k = 0; k < CD; ++k)
+          if (k < nch) w -= bg[k] * v[k];
+      }
+      W = T * w;
+    }
+    // vC operand: transpose each 32-channel block through LDS (pixel-major rows of 33 floats), read back by channel
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int k = 0; k < 32; ++k) F.tr[lane * 33 + k] = v[32 * nt + k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int p0 = 16 * s4 + 8 * mh + 2 * i;
+          split_pair(F.tr[p0 * 33 + mrow], F.tr[(p0 + 1) * 33 + mrow], vbh[nt][s4][i], vbl[nt][s4][i]);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned xh, xl, yh, yl;
+        split_pair(v[16 * ks + 2 * i], v[16 * ks + 2 * i + 1], xh, xl);
+        split_pair(v[16 * ks + 8 + 2 * i], v[16 * ks + 9 + 2 * i], yh, yl);
+        swap32(xh, yh, b0h[ks][i], b1h[ks][i]);
+        swap32(xl, yl, b0l[ks][i], b1l[ks][i]);
+      }
+#pragma unroll
+    for (int k = 0; k < CV; ++k) vrest[k] = v[CM + k];
+#pragma unroll
+    for (int k = 0; k < CR; ++k) crest[k] = v[CC + k];
+  }
+  int max_last = last;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) max_last = max(max_last, __shfl_xor(max_last, m));
+
+  // lane v < 8 + CR owns reduced value v (0-7 geometry, 8.. rest colours): its 16 partials sit in one red row
+  const int own_q = lane >> 2, own_row = ((lane & 1) << 1) | ((lane >> 1) & 1);
+  const float4 *own = reinterpret_cast<const float4 *>(red + own_q * 68 + own_row * 16);
+  const float gscale = (lane == 0 || lane == 1) ? -LN2 : (lane == 2 || lane == 4) ? 0.5f
+                       : (lane == 6 || lane == 7) ? LN2 : 1.f;
+  const int n_geo = absgrad ? 8 : 6;
+  // gradient destinations: channel tile nt, column mrow (matrix part); channel CC + lane - 8 (vector part)
+  float *mcol[NT];
+  int mld[NT];
+  bool mshared[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ch = 32 * nt + mrow;
+    const int sgm = ch >= gs.begin[2] ? 2 : ch >= gs.begin[1] ? 1 : 0;
+    float *p = gs.ptr[sgm];
+    mcol[nt] = (p && ch < nch) ? p + (ch - gs.begin[sgm]) : nullptr;
+    mld[nt] = gs.ld[sgm];
+    mshared[nt] = gs.shared[sgm] != 0;
+  }
+  float *rcol = nullptr;
+  int rld = 0;
+  bool rshared = false;
+  if (CR > 0 && lane >= 8 && lane < 8 + CR) {
+    const int ch = CC + lane - 8;
+    const int sgm = ch >= gs.begin[2] ? 2 : ch >= gs.begin[1] ? 1 : 0;
+    float *p = gs.ptr[sgm];
+    rcol = (p && ch < nch) ? p + (ch - gs.begin[sgm]) : nullptr;
+    rld = gs.ld[sgm];
+    rshared = gs.shared[sgm] != 0;
+  }
+  const int cam_first = cam * N;
+
+  const float rx0 = (float)(tx * 16) + 0.5f, ry0 = (float)(ty * 16 + sub * Rg::RH) + 0.5f;
+  const float rx1 = (float)min(tx * 16 + 16, width) - 0.5f;
+  const float ry1 = (float)min(ty * 16 + sub * Rg::RH + Rg::RH, height) - 0.5f;
+  BatchGeometry pre = prefetch_batch(lane, max(range_lo, max_last - BS), max_last - max(range_lo, max_last - BS),
+                                     flatten_ids, means2d, conics, opacities);
+  for (int bend = max_last; bend > range_lo; bend -= BS) {
+    const int first = max(range_lo, bend - BS);
+    const unsigned long long todo = stage_batch<CD, false, BS>(L, lane, pre, cs, N, D, 0, rx0, ry0, rx1, ry1);
+    {
+      const int nend = bend - BS, nfirst = max(range_lo, nend - BS);
+      pre = prefetch_batch(lane, nfirst, nend - nfirst, flatten_ids, means2d, conics, opacities);
+    }
+    if (todo == 0ull) continue;
+    // (1) S for every staged slot and every pixel of the region
+    f16v s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s0[r] = 0.f, s1[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 *row = reinterpret_cast<const float4 *>(L.col + mrow * ROW + 16 * ks + 8 * mh);
+      const float4 c0 = row[0], c1 = row[1];
+      unsigned ah[4], al[4];
+      split_pair(c0.x, c0.y, ah[0], al[0]);
+      split_pair(c0.z, c0.w, ah[1], al[1]);
+      split_pair(c1.x, c1.y, ah[2], al[2]);
+      split_pair(c1.z, c1.w, ah[3], al[3]);
+      s0 = mfma_bf16(ah, b0h[ks], s0);
+      s1 = mfma_bf16(ah, b1h[ks], s1);
+      s0 = mfma_bf16(al, b0h[ks], s0);
+      s1 = mfma_bf16(al, b1h[ks], s1);
+      s0 = mfma_bf16(ah, b0l[ks], s0);
+      s1 = mfma_bf16(ah, b1l[ks], s1);
+    }
+    float sa[16], sb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      // inline assembly on purpose: see raster_bwd_geom_mfma_kernel
+      float fa = s0[r], fb = s1[r];
+      asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(fa), "+v"(fb));
+      sa[r] = fa;
+      sb[r] = fb;
+    }
+    unsigned contributed = 0u;  // slots of this batch that some pixel of the region took
+#pragma unroll
+    for (int t = BS - 1; t >= 0; --t) {
+      if (!((todo >> t) & 1ull)) continue;
+      const int idx = first + t;
+      const float4 g = L.g4[t];
+      const float2 h = L.g2[t];
+      const float dx = g.x - px0, dy = g.y - py0;
+      const float power = g.w * dx * dx + h.y * dy * dy + h.x * dx * dy;
+      const float e = __builtin_amdgcn_exp2f(power), ar = g.z * e;
+      const float a = fminf(ALPHA_MAX, ar);
+      const bool active = (power <= 0.f) && (a >= ALPHA_MIN) && (idx < last);
+      if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
+      contributed |= 1u << t;
+      const float alpha = active ? a : 0.f;
+      float S = ((t >> 2) & 1) ? sb[(t & 3) + 4 * (t >> 3)] : sa[(t & 3) + 4 * (t >> 3)];
+      if (CV > 0) {
+        const float4 *crow = reinterpret_cast<const float4 *>(L.col + t * ROW + CM);
+#pragma unroll
+        for (int q = 0; q < CV / 4; ++q) {
+          const float4 c = crow[q];
+          S = fmaf(c.x, vrest[4 * q], S);
+          S = fmaf(c.y, vrest[4 * q + 1], S);
+          S = fmaf(c.z, vrest[4 * q + 2], S);
+          S = fmaf(c.w, vrest[4 * q + 3], S);
+        }
+      }
+      const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+      T *= ra;
+      const float fac = alpha * T;
+      {  // this pixel's entry of row t of the fac image
+        unsigned fh, fl;
+        split_pair(fac, 0.f, fh, fl);
+        F.f.hi[t * FP + lane] = (unsigned short)fh;
+        F.f.lo[t * FP + lane] = (unsigned short)fl;
+      }
+      const float v_alpha = S * T - (Bsum - W) * ra;
+      Bsum = fmaf(fac, S, Bsum);
+      const float ev = (alpha == ar ? e : 0.f) * v_alpha;
+      const float vs = -g.z * ev;
+      const float t1 = vs * dx, t2 = vs * dy;
+      const float gx = 2.f * g.w * dx + h.x * dy, gy = h.x * dx + 2.f * h.y * dy;
+      const float vx = vs * gx, vy = vs * gy;
+      red[lane] = quad_fold_rows(vx, vy, t1 * dx, t1 * dy);
+      red[68 + lane] = quad_fold_rows(t2 * dy, ev, fabsf(vx), fabsf(vy));
+#pragma unroll
+      for (int q = 0; q < NQR; ++q)
+        red[(2 + q) * 68 + lane] = quad_fold_rows(fac * crest[4 * q], fac * crest[4 * q + 1], fac * crest[4 * q + 2],
+                                                  fac * crest[4 * q + 3]);
+      const int gid = L.ids[t];
+      if (lane < 8 + CR) {
+        const float4 p0 = own[0], p1 = own[1], p2 = own[2], p3 = own[3];
+        const float tot = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w)) +
+                          ((p2.x + p2.y) + (p2.z + p2.w)) + ((p3.x + p3.y) + (p3.z + p3.w));
+        if (lane < n_geo) atomic_add_noret(v_geom + (int64_t)gid * 8 + lane, tot * gscale);
+        if (CR > 0 && lane >= 8 && rcol) atomic_add_noret(rcol + (int64_t)(rshared ? gid - cam_first : gid) * rld, tot);
+      }
+    }
+    if (contributed == 0u) continue;
+    // (2) vC[slot][channel] = sum over the region's 64 pixels of fac * v, rows = slots
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f16v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const u4v ah4 = *reinterpret_cast<const u4v *>(&F.f.hi[mrow * FP + 16 * s4 + 8 * mh]);
+        const u4v al4 = *reinterpret_cast<const u4v *>(&F.f.lo[mrow * FP + 16 * s4 + 8 * mh]);
+        const unsigned ah[4] = {ah4[0], ah4[1], ah4[2], ah4[3]}, al[4] = {al4[0], al4[1], al4[2], al4[3]};
+        acc = mfma_bf16(ah, vbh[nt][s4], acc);
+        acc = mfma_bf16(al, vbh[nt][s4], acc);
+        acc = mfma_bf16(ah, vbl[nt][s4], acc);
+      }
+      float *dst = mcol[nt];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int slot = (r & 3) + 8 * (r >> 2) + 4 * mh;
+        if (dst && ((contributed >> slot) & 1u)) {
+          const int gid = L.ids[slot];
+          atomic_add_noret(dst + (int64_t)(mshared[nt] ? gid - cam_first : gid) * mld[nt], acc[r]);
+        }
+      }
+    }
+  }
+}
+
+template <int CD>
+static int launch_bwd_full_mfma(int C, int N, int D, const float *means2d, const float *conics, const ColorSegs &cs,
+                                const float *opacities, const float *backgrounds, int width, int height, int tile_w,
+                                int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
+                                const int32_t *flatten_ids, int64_t n_isects, const float *render_alphas,
+                                const int32_t *last_ids, const float *render_colors, int ed_channel,
+                                const float *v_render_colors, const float *v_render_alphas, int absgrad, float *v_geom,
+                                const GradSegs &gs, hipStream_t stream) {
+  const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<16, 1>::WPT;
+  const unsigned grid = region_grid(n_regions, Region<16, 1>::WPT, tile_order != nullptr);
+  hipLaunchKernelGGL((raster_bwd_full_mfma_kernel<CD>), dim3(grid), dim3(64), 0, stream, (int)n_regions, N, D, means2d,
+                     conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets, tile_order,
+                     flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors,
+                     v_render_alphas, absgrad, v_geom, gs);
+  return check_launch("raster_bwd_full_mfma_kernel");
+}
+
 #ifdef PR_DIAG
 extern "C" int pr_diag_read(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pr::g_diag), sizeof(pr::g_diag)) != hipSuccess) return -4;
@@ -712,6 +1027,22 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
       default: break;  // narrower or wider passes: the vector kernels below
     }
 #undef GEOM_MFMA_ARGS
+  }
+  // geometry + colour gradients with both contractions on the matrix cores (1 pixel per lane)
+  if (geom_grad && any_color_grad && tile_size == 16 && tuning().bwd_mfma == 2 && plan.per == D) {
+    const int cd = pick_chunk(D);
+#define FULL_MFMA_ARGS                                                                                             \
+  C, N, D, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets, tile_order, \
+      flatten_ids, n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas, \
+      absgrad, v_geom, gs, (hipStream_t)stream
+    switch (cd) {
+      case 32: return launch_bwd_full_mfma<32>(FULL_MFMA_ARGS);
+      case 36: return launch_bwd_full_mfma<36>(FULL_MFMA_ARGS);
+      case 64: return launch_bwd_full_mfma<64>(FULL_MFMA_ARGS);
+      case 72: return launch_bwd_full_mfma<72>(FULL_MFMA_ARGS);
+      default: break;
+    }
+#undef FULL_MFMA_ARGS
   }
   for (int off = 0; off < D; off += plan.per) {
     const int cd = pick_chunk(min(plan.per, D - off));

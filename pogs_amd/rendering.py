@@ -14,6 +14,7 @@ costs one projection, one binning and one walk over the tile lists instead of tw
 from __future__ import annotations
 
 import math
+import os
 import threading
 from typing import Dict, List, Optional, Tuple
 
@@ -36,8 +37,9 @@ class StageTimer:
     """Optional per-entry-point device timing: HIP events recorded on the stream the kernels are launched
     on (torch's current stream), read back after a synchronise.  Used by bench.py for the roofline line."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.spans = {}
+        self.only = None if only is None else set(only)   # time these entry points only (events are not free)
 
     def record(self, name):
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -60,7 +62,7 @@ def set_stage_timer(timer: Optional[StageTimer]) -> None:
 def _call(name: str, *args) -> None:
     """Invoke one C-ABI entry point, raising RuntimeError on a non-zero status."""
     fn = getattr(_lib.load(), name)
-    if _timer is None:
+    if _timer is None or (_timer.only is not None and name not in _timer.only):
         _lib.check(fn(*args), name)
         return
     a, b = _timer.record(name)
@@ -209,7 +211,7 @@ class _CallState:
         self.history: Dict[tuple, List[int]] = {}
         self.pinned: Dict[int, List[Tensor]] = {}
         self.side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
-        self.speculate = True
+        self.speculate = os.environ.get("POGS_RAST_SPECULATE", "1") != "0"
 
     def guess(self, key) -> Optional[int]:
         """Capacity to size the lists with, or None when the host should wait for the exact count."""
@@ -529,8 +531,23 @@ class _Rasterize(torch.autograd.Function):
             v_render_alphas = torch.zeros(C, height, width, 1, dtype=torch.float32, device=dev)
         v_render_colors, v_render_alphas = v_render_colors.contiguous(), v_render_alphas.contiguous()
         geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[5]
-        v_geom = torch.zeros(C * N, 8, dtype=torch.float32, device=dev) if geom else None
-        v_parts = [torch.zeros_like(p) if ctx.needs_input_grad[2 + slot] else None for p, slot in zip(parts, slots)]
+        # the accumulation targets start at zero: the packed geometry gradients and the narrow colour parts (rgb, depth)
+        # share one allocation and one fill; wide parts (features) get their own
+        want = [bool(ctx.needs_input_grad[2 + slot]) for slot in slots]
+        pooled = [w and p.shape[-1] <= 4 for w, p in zip(want, parts)]
+        n_pool = (C * N * 8 if geom else 0) + sum((p.numel() + 7) // 8 * 8 for p, k in zip(parts, pooled) if k)
+        pool = torch.zeros(n_pool, dtype=torch.float32, device=dev) if n_pool else None
+        at = C * N * 8 if geom else 0
+        v_geom = pool[:at].view(C * N, 8) if geom else None
+        v_parts = []
+        for p, w, k in zip(parts, want, pooled):
+            if not w:
+                v_parts.append(None)
+            elif k:
+                v_parts.append(pool[at:at + p.numel()].view(p.shape))
+                at += (p.numel() + 7) // 8 * 8
+            else:
+                v_parts.append(torch.zeros_like(p))
         if geom or any(v is not None for v in v_parts):
             single = len(parts) == 1 and not items[0][3]
             keep_c, segs = (None, None) if single else _lib.segment_array(items)
@@ -592,26 +609,27 @@ def fully_fused_projection(means, quats, scales, viewmats, Ks, width, height, ep
 class _CameraCenters(torch.autograd.Function):
     """c = inverse(V)[:, :3, 3] for rigid world->camera matrices V.  Forward uses the closed form -R^T t;
     backward is the derivative of the general matrix inverse, dM = -M dV M, so gradients equal those of
-    ``torch.inverse(viewmats)[:, :3, 3]`` (what gsplat's ``rasterization`` differentiates through)."""
+    ``torch.inverse(viewmats)[:, :3, 3]`` (what gsplat's ``rasterization`` differentiates through).  One small
+    kernel each way (``pr_campos_fwd`` / ``pr_campos_bwd``)."""
 
     @staticmethod
     def forward(ctx, viewmats):
-        R = viewmats[:, :3, :3]
-        t = viewmats[:, :3, 3:4]
-        M = torch.zeros_like(viewmats)
-        M[:, :3, :3] = R.transpose(1, 2)
-        M[:, :3, 3:4] = -(R.transpose(1, 2) @ t)
-        M[:, 3, 3] = 1.0
-        ctx.save_for_backward(M)
-        return M[:, :3, 3].clone()
+        viewmats = viewmats.contiguous()
+        C = viewmats.shape[0]
+        campos = torch.empty(C, 3, dtype=torch.float32, device=viewmats.device)
+        with torch.cuda.device(viewmats.device):
+            _call("pr_campos_fwd", C, _ptr(viewmats), _ptr(campos), _stream())
+        ctx.save_for_backward(viewmats)
+        return campos
 
     @staticmethod
     def backward(ctx, v_c):
-        (M,) = ctx.saved_tensors
-        v_M = torch.zeros_like(M)
-        v_M[:, :3, 3] = v_c
-        Mt = M.transpose(1, 2)
-        return -(Mt @ v_M @ Mt)
+        (viewmats,) = ctx.saved_tensors
+        C = viewmats.shape[0]
+        v_viewmats = torch.empty_like(viewmats)
+        with torch.cuda.device(viewmats.device):
+            _call("pr_campos_bwd", C, _ptr(viewmats), _ptr(v_c.contiguous()), _ptr(v_viewmats), _stream())
+        return v_viewmats
 
 
 def camera_centers(viewmats: Tensor) -> Tensor:
