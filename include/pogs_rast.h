@@ -125,6 +125,24 @@ int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii,
                        int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets, int32_t *tile_order,
                        const int64_t *n_isects_dev, const int32_t *depth_order, void *scratch,
                        size_t scratch_bytes, void *stream);
+/* The compositor's lists in two calls, without a device-wide sort: what `isect_tiles` + `isect_offset_encode` produce
+ * for the pairs that can contribute (conics/opacities required: the footprint-tested rule of pr_isect_count), in the
+ * same order (camera, tile, depth bits, flat index), but WITHOUT gsplat's 64-bit keys.
+ * pr_tile_lists_count: tile_counters[C*tile_h*tile_w] int32 is working memory carried to pr_tile_lists_fill;
+ *   out: isect_offsets[C,tile_h,tile_w], *n_isects_dev (device int64: the total, to be read back by the caller to size
+ *   the lists), tile_order (may be NULL; as in pr_isect_emit_sort), tiles_per_gauss[C,N] (may be NULL).
+ * pr_tile_lists_fill: capacity = entries flatten_ids and keys_scratch (uint64 each) hold; a caller that sized them
+ *   from a guess compares *n_isects_dev with it afterwards -- when the total is larger the lists are incomplete
+ *   (never out of bounds) and both calls must be repeated.  The same means2d/radii/conics/opacities must be given
+ *   to both calls.  No gsplat counterpart as separate routines. */
+int pr_tile_lists_count(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
+                        const float *opacities, int tile_size, int tile_w, int tile_h, int32_t *tiles_per_gauss,
+                        int32_t *tile_counters, int32_t *isect_offsets, int32_t *tile_order, int64_t *n_isects_dev,
+                        void *stream);
+int pr_tile_lists_fill(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                       const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                       const int32_t *isect_offsets, int32_t *tile_counters, int64_t capacity,
+                       const int64_t *n_isects_dev, uint64_t *keys_scratch, int32_t *flatten_ids, void *stream);
 /* depth_order[C*N] int32: the flat indices c*N+n in stable ascending order of the depths' float bits (ties by
  * ascending index) -- the first level of phase 2's two-level sort, split out because it depends on the
  * projection only: a caller may run it on another stream while colours are evaluated and tiles counted. */

@@ -120,7 +120,7 @@ struct alignas(16) WaveRecords {
   float4 ga[WAVE];     // gx, gy, opacity, conic a
   float4 gb[WAVE];     // conic b, conic c, 1/w, bit_cast(x0 | y0 << 16)
   int2 gc[WAVE];       // first candidate number, w
-  uint2 gd[WAVE];      // camera bits of the key, flat Gaussian index
+  uint2 gd[WAVE];      // camera bits of the key (or the camera's first flat tile index), flat Gaussian index
   int owner[WAVE];     // scratch for the owner search of one chunk of 64 candidates
 };
 
@@ -255,6 +255,177 @@ __global__ void __launch_bounds__(256) isect_emit_tight_kernel(
       }
     }
     pos += __builtin_popcountll(m);
+  }
+}
+
+// ---- binning straight into per-tile lists (the render path) ---------------------------------------------------
+// What the compositor needs is, per tile, the flat indices of the Gaussians that can contribute, ordered by (depth
+// bits, flat index).  The two-level sort above reaches that order with four radix passes over the C*N depth keys and
+// two over the intersections, every one of them a small latency-bound launch.  Here instead:
+//   1. tile_lists_count_kernel: the footprint-tested enumeration of isect_count_tight_kernel, which also bumps a
+//      counter per (camera, tile);
+//   2. tile_lists_scan_kernel (one workgroup): exclusive scan of the counters -> isect_offsets and the total; counters
+//      reset to zero; launch order of the tiles (heaviest first);
+//   3. tile_lists_emit_kernel: the same enumeration again; each kept pair takes the next free slot of its tile's list
+//      (returning atomic on the tile's counter) and stores the 64-bit key depth_bits << 32 | flat_index there --
+//      unordered within the tile;
+//   4. tile_lists_sort_kernel: one workgroup per tile sorts its list in LDS (bitonic network on the 64-bit keys, which
+//      are unique, so the result does not depend on the order the slots were handed out) and writes the indices.
+// The order is the one a stable sort by (camera, tile, depth bits) of index-ordered intersections gives: gsplat's.
+__global__ void __launch_bounds__(256) tile_lists_count_kernel(
+    int64_t total, int N, int n_tiles, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+    const float *__restrict__ conics, const float *__restrict__ opacities, float ts, int tile_w, int tile_h,
+    int32_t *__restrict__ tiles_per_gauss, int32_t *__restrict__ tile_counts) {
+  __shared__ WaveRecords recs[4];
+  __shared__ int counts[256];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  WaveRecords &R = recs[threadIdx.x >> 6];
+  int *mine = counts + (threadIdx.x & ~63);
+  mine[lane] = 0;
+  int cnt, cstart;
+  const uint32_t tile_base = idx < total ? (uint32_t)(idx / N) * (uint32_t)n_tiles : 0u;
+  const int n_cand = load_records(R, idx < total, idx, tile_base, means2d, radii, conics, opacities, ts, tile_w, tile_h,
+                                  lane, cnt, cstart);
+  int carry = 0;
+  for (int c0 = 0; c0 < n_cand; c0 += WAVE) {
+    int j, tx, ty;
+    if (test_chunk(R, c0, n_cand, lane, cnt, cstart, ts, carry, j, tx, ty)) {
+      if (tiles_per_gauss) atomicAdd(&mine[j], 1);
+      atomicAdd(&tile_counts[R.gd[j].x + (uint32_t)(ty * tile_w + tx)], 1);
+    }
+  }
+  if (tiles_per_gauss && idx < total) tiles_per_gauss[idx] = mine[lane];
+}
+
+__device__ void tile_order_body(int n_tiles_total, const int32_t *__restrict__ offsets, int64_t n_isects,
+                                int32_t *__restrict__ order);
+
+// counts[t] -> offsets[t] (exclusive), *n_isects_dev = total, counts[t] = 0 (they become the emission's cursors),
+// and, when asked for, the launch order of the tiles.  One workgroup of 1024 threads.
+__global__ void __launch_bounds__(1024) tile_lists_scan_kernel(int n_tiles_total, int32_t *__restrict__ counts,
+                                                               int32_t *__restrict__ offsets,
+                                                               int64_t *__restrict__ n_isects_dev,
+                                                               int32_t *__restrict__ order) {
+  __shared__ long long part[1024];
+  const int tid = threadIdx.x;
+  const int chunk = (n_tiles_total + 1023) / 1024;
+  const int lo = min(tid * chunk, n_tiles_total), hi = min(lo + chunk, n_tiles_total);
+  long long sum = 0;
+  for (int t = lo; t < hi; ++t) sum += counts[t];
+  part[tid] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {   // inclusive scan of the 1024 partial sums
+    const long long up = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += up;
+    __syncthreads();
+  }
+  const long long total = part[1023];
+  long long run = part[tid] - sum;
+  for (int t = lo; t < hi; ++t) {
+    const int c = counts[t];
+    offsets[t] = (int32_t)(run < 2147483647ll ? run : 2147483647ll);
+    counts[t] = 0;
+    run += c;
+  }
+  if (tid == 0) *n_isects_dev = total;
+  if (order) {
+    __threadfence_block();
+    __syncthreads();
+    tile_order_body(n_tiles_total, offsets, total, order);
+  }
+}
+
+__global__ void __launch_bounds__(256) tile_lists_emit_kernel(
+    int64_t total, int N, int n_tiles, const float *__restrict__ means2d, const int32_t *__restrict__ radii,
+    const float *__restrict__ depths, const float *__restrict__ conics, const float *__restrict__ opacities, float ts,
+    int tile_w, int tile_h, const int32_t *__restrict__ offsets, int32_t *__restrict__ cursors, int64_t cap,
+    unsigned long long *__restrict__ keys) {
+  __shared__ WaveRecords recs[4];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  WaveRecords &R = recs[threadIdx.x >> 6];
+  int cnt, cstart;
+  const uint32_t tile_base = idx < total ? (uint32_t)(idx / N) * (uint32_t)n_tiles : 0u;
+  const int n_cand = load_records(R, idx < total, idx, tile_base, means2d, radii, conics, opacities, ts, tile_w, tile_h,
+                                  lane, cnt, cstart);
+  int carry = 0;
+  for (int c0 = 0; c0 < n_cand; c0 += WAVE) {
+    int j, tx, ty;
+    if (test_chunk(R, c0, n_cand, lane, cnt, cstart, ts, carry, j, tx, ty)) {
+      const uint2 gd = R.gd[j];
+      const uint32_t tile = gd.x + (uint32_t)(ty * tile_w + tx);
+      const int64_t pos = (int64_t)offsets[tile] + atomicAdd(&cursors[tile], 1);
+      if (pos < cap)
+        keys[pos] = ((unsigned long long)(uint32_t)__float_as_int(depths[gd.y]) << 32) | (unsigned long long)gd.y;
+    }
+  }
+}
+
+// Ascending bitonic network with every comparator pointing the same way (the first step of each merge pairs i with
+// its mirror image in the block), so positions >= n behave as +infinity without being stored: a comparator whose
+// upper end lies beyond n never swaps.
+template <class Keys>
+__device__ __forceinline__ void bitonic_sort_block(Keys keys, int n, int tid, int n_threads) {
+  int P = 1;
+  while (P < n) P <<= 1;
+  for (int k = 2; k <= P; k <<= 1) {
+    const int half = k >> 1;
+    for (int i = tid; i < (P >> 1); i += n_threads) {
+      const int lo = (i / half) * k + (i % half), hi = (i / half) * k + k - 1 - (i % half);
+      if (hi < n) {
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if (a > b) {
+          keys[lo] = b;
+          keys[hi] = a;
+        }
+      }
+    }
+    __syncthreads();
+    for (int j = half >> 1; j >= 1; j >>= 1) {
+      for (int i = tid; i < (P >> 1); i += n_threads) {
+        const int lo = (i / j) * 2 * j + (i % j), hi = lo + j;
+        if (hi < n) {
+          const unsigned long long a = keys[lo], b = keys[hi];
+          if (a > b) {
+            keys[lo] = b;
+            keys[hi] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+constexpr int TILE_SORT_LDS = 4096;   // list lengths sorted in LDS (32 KB); longer lists are sorted in global memory
+__global__ void __launch_bounds__(256) tile_lists_sort_kernel(int n_tiles_total, const int32_t *__restrict__ offsets,
+                                                              int64_t cap, const int64_t *__restrict__ n_isects_dev,
+                                                              unsigned long long *__restrict__ keys,
+                                                              int32_t *__restrict__ flatten_ids) {
+  __shared__ unsigned long long buf[TILE_SORT_LDS];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int64_t n_all = *n_isects_dev < cap ? *n_isects_dev : cap;
+  const int64_t begin = offsets[t] < n_all ? offsets[t] : n_all;
+  int64_t end = t + 1 < n_tiles_total ? (int64_t)offsets[t + 1] : n_all;
+  if (end > n_all) end = n_all;
+  const int n = (int)(end - begin);
+  if (n <= 0) return;
+  unsigned long long *list = keys + begin;
+  if (n <= TILE_SORT_LDS) {
+    for (int i = tid; i < n; i += 256) buf[i] = list[i];
+    __syncthreads();
+    bitonic_sort_block(buf, n, tid, 256);
+    for (int i = tid; i < n; i += 256) flatten_ids[begin + i] = (int32_t)(uint32_t)buf[i];
+  } else {
+    // rare: a list too long for LDS is sorted where it lies (the workgroup's own stores, made visible to its other
+    // wavefronts by the barrier's fence; volatile keeps the compiler from caching elements in registers)
+    volatile unsigned long long *g = list;
+    __syncthreads();
+    bitonic_sort_block(g, n, tid, 256);
+    __threadfence_block();
+    for (int i = tid; i < n; i += 256) flatten_ids[begin + i] = (int32_t)(uint32_t)g[i];
   }
 }
 
@@ -467,15 +638,14 @@ __global__ void __launch_bounds__(256) tile_offsets_kernel(int64_t cap, const in
 // Launch order of the compositing kernels: tiles by list length, longest first.  Only the rough order
 // matters (it shortens the tail of the launch), so one workgroup buckets the tiles by length -- 1024 linear
 // buckets between 0 and the longest list -- instead of a full device sort (six small kernels for ~8k keys).
-__global__ void __launch_bounds__(1024) tile_order_kernel(int n_tiles_total, const int32_t *__restrict__ offsets,
-                                                          int64_t cap, const int64_t *__restrict__ n_dev,
-                                                          int32_t *__restrict__ order) {
+namespace pr {
+__device__ void tile_order_body(int n_tiles_total, const int32_t *__restrict__ offsets, int64_t n_isects,
+                                int32_t *__restrict__ order) {
   constexpr int NB = 1024;
   __shared__ int bucket[NB];
   __shared__ int wave_part[16];
   __shared__ int longest;
   const int tid = threadIdx.x;
-  const int64_t n_isects = true_count(cap, n_dev);
   auto length = [&](int t) {
     const int32_t hi = t + 1 < n_tiles_total ? offsets[t + 1] : (int32_t)n_isects;
     return hi - offsets[t];
@@ -508,6 +678,13 @@ __global__ void __launch_bounds__(1024) tile_order_kernel(int n_tiles_total, con
   __syncthreads();
   for (int t = tid; t < n_tiles_total; t += NB)
     order[atomicAdd(&bucket[(int)((float)(longest - length(t)) * scale)], 1)] = t;
+}
+}  // namespace pr
+
+__global__ void __launch_bounds__(1024) tile_order_kernel(int n_tiles_total, const int32_t *__restrict__ offsets,
+                                                          int64_t cap, const int64_t *__restrict__ n_dev,
+                                                          int32_t *__restrict__ order) {
+  tile_order_body(n_tiles_total, offsets, true_count(cap, n_dev), order);
 }
 
 __global__ void __launch_bounds__(256) isect_ids_kernel(int64_t cap, const int64_t *__restrict__ n_dev,
@@ -709,6 +886,54 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
     rc = check_launch("isect_ids_kernel");
   }
   return rc;
+}
+
+extern "C" int pr_tile_lists_count(int C, int N, const float *means2d, const int32_t *radii, const float *conics,
+                                   const float *opacities, int tile_size, int tile_w, int tile_h,
+                                   int32_t *tiles_per_gauss, int32_t *tile_counters, int32_t *isect_offsets,
+                                   int32_t *tile_order, int64_t *n_isects_dev, void *stream) {
+  if (C < 0 || N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return PR_EINVAL;
+  const int64_t total = (int64_t)C * N, n_tiles_total = (int64_t)C * tile_w * tile_h;
+  if (total > (int64_t)2147483647 || n_tiles_total > (int64_t)2147483647) return PR_EUNSUPPORTED;
+  if (n_tiles_total == 0) return PR_OK;
+  if (!tile_counters || !isect_offsets || !n_isects_dev) return PR_EINVAL;
+  if (total > 0 && (!means2d || !radii || !conics || !opacities)) return PR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  PR_HIP(hipMemsetAsync(tile_counters, 0, (size_t)n_tiles_total * 4, st));
+  if (total > 0) {
+    hipLaunchKernelGGL(tile_lists_count_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, N,
+                       tile_w * tile_h, means2d, radii, conics, opacities, (float)tile_size, tile_w, tile_h,
+                       tiles_per_gauss, tile_counters);
+    const int rc = check_launch("tile_lists_count_kernel");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(tile_lists_scan_kernel, dim3(1), dim3(1024), 0, st, (int)n_tiles_total, tile_counters,
+                     isect_offsets, n_isects_dev, tile_order);
+  return check_launch("tile_lists_scan_kernel");
+}
+
+extern "C" int pr_tile_lists_fill(int C, int N, const float *means2d, const int32_t *radii, const float *depths,
+                                  const float *conics, const float *opacities, int tile_size, int tile_w, int tile_h,
+                                  const int32_t *isect_offsets, int32_t *tile_counters, int64_t capacity,
+                                  const int64_t *n_isects_dev, uint64_t *keys_scratch, int32_t *flatten_ids,
+                                  void *stream) {
+  if (C < 0 || N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || capacity < 0) return PR_EINVAL;
+  const int64_t total = (int64_t)C * N, n_tiles_total = (int64_t)C * tile_w * tile_h;
+  if (total > (int64_t)2147483647 || n_tiles_total > (int64_t)2147483647 || capacity > (int64_t)2147483647)
+    return PR_EUNSUPPORTED;
+  if (total == 0 || capacity == 0 || n_tiles_total == 0) return PR_OK;
+  if (!means2d || !radii || !depths || !conics || !opacities || !isect_offsets || !tile_counters || !n_isects_dev ||
+      !keys_scratch || !flatten_ids)
+    return PR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(tile_lists_emit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, N,
+                     tile_w * tile_h, means2d, radii, depths, conics, opacities, (float)tile_size, tile_w, tile_h,
+                     isect_offsets, tile_counters, capacity, (unsigned long long *)keys_scratch);
+  int rc = check_launch("tile_lists_emit_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(tile_lists_sort_kernel, dim3((unsigned)n_tiles_total), dim3(256), 0, st, (int)n_tiles_total,
+                     isect_offsets, capacity, n_isects_dev, (unsigned long long *)keys_scratch, flatten_ids);
+  return check_launch("tile_lists_sort_kernel");
 }
 
 extern "C" int pr_isect_offsets(int64_t n_isects, const int64_t *isect_ids, int C, int tile_w, int tile_h,

@@ -192,6 +192,11 @@ class _SphericalHarmonics(torch.autograd.Function):
 
 _ORDER_MIN_TILES = 2048  # fewer tiles than wave slots: nothing to balance
 _ASYNC_DEPTH_ORDER_MIN = 100_000
+# POGS_RAST_BINNING=lists builds the per-tile lists with per-tile counters and one LDS sort per tile instead of the
+# two-level device sort.  Measured at 1M Gaussians / 1080p it is SLOWER (0.66 ms against 0.50 ms): 6.4M scattered
+# integer atomics cost 0.18 ms in the counting pass and again in the emission.  Kept for small scenes and as a
+# cross-check of the sorted lists (tests compare the two).
+_TILE_LISTS = os.environ.get("POGS_RAST_BINNING", "sort") == "lists"
 
 
 class _CallState:
@@ -368,6 +373,64 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
     if want_order:
         return tiles_per_gauss, isect_ids, flatten_ids, offsets, order
     return tiles_per_gauss, isect_ids, flatten_ids, offsets
+
+
+def _tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, opacities: Tensor, tile_size: int,
+                tile_width: int, tile_height: int, want_order: bool = True):
+    """The compositor's lists without a device-wide sort (``pr_tile_lists_count`` / ``pr_tile_lists_fill``): only the
+    (Gaussian, tile) pairs that can reach alpha >= 1/255 in the tile, per tile in (depth bits, flat index) order.
+    -> (flatten_ids [I] int32, isect_offsets [C,th,tw] int32, tile_order [C*th*tw] int32 or None)."""
+    lib = _lib.load()
+    C, N = radii.shape
+    dev = means2d.device
+    means2d, radii, depths = means2d.detach().contiguous(), radii.contiguous(), depths.detach().contiguous()
+    conics, opacities = conics.detach().contiguous(), opacities.detach().contiguous()
+    n_tiles = C * tile_height * tile_width
+    offsets = torch.empty(C, tile_height, tile_width, dtype=torch.int32, device=dev)
+    order = None
+    if want_order and n_tiles >= _ORDER_MIN_TILES and C * N > 0:
+        order = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+    if C * N == 0 or n_tiles == 0:
+        offsets.zero_()
+        return torch.empty(0, dtype=torch.int32, device=dev), offsets, None
+    counters = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _call("pr_tile_lists_count", C, N, _ptr(means2d), _ptr(radii), _ptr(conics), _ptr(opacities), tile_size,
+              tile_width, tile_height, None, _ptr(counters), _ptr(offsets), _ptr(order), _ptr(total), _stream())
+
+        def fill(capacity):
+            flat = torch.empty(capacity, dtype=torch.int32, device=dev)
+            keys = torch.empty(capacity, dtype=torch.int64, device=dev)
+            _call("pr_tile_lists_fill", C, N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(conics), _ptr(opacities),
+                  tile_size, tile_width, tile_height, _ptr(offsets), _ptr(counters), capacity, _ptr(total), _ptr(keys),
+                  _ptr(flat), _stream())
+            return flat
+
+        # list sizes: from the counts of earlier calls when they are settled (see _CallState), else wait for the total
+        key = (dev.index, C, N, tile_size, tile_width, tile_height, "lists")
+        guess = _state.guess(key)
+        if guess is None:
+            n_isects = int(total.item())
+            flatten_ids = fill(n_isects)
+        else:
+            host = _state.take_pinned(dev)
+            host.copy_(total, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            flatten_ids = fill(guess)
+            done.synchronize()
+            n_isects = int(host.item())
+            _state.give_pinned(dev, host)
+            if n_isects > guess:      # the counters were consumed by the undersized fill: count again
+                _call("pr_tile_lists_count", C, N, _ptr(means2d), _ptr(radii), _ptr(conics), _ptr(opacities),
+                      tile_size, tile_width, tile_height, None, _ptr(counters), _ptr(offsets), _ptr(order),
+                      _ptr(total), _stream())
+                flatten_ids = fill(n_isects)
+            else:
+                flatten_ids = flatten_ids[:n_isects]
+        _state.record(key, n_isects, guess is not None and n_isects > guess)
+    return flatten_ids, offsets, order
 
 
 def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
@@ -688,8 +751,8 @@ def rasterization(
     radii, means2d, depths, conics, compensations = fully_fused_projection(
         means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
         calc_compensations=(rasterize_mode == "antialiased"))
-    # small models: the second stream's hand-offs cost more than the overlap gains
-    depth_order = _depth_order_async(depths) if C * N >= _ASYNC_DEPTH_ORDER_MIN else None
+    # the two-level device sort runs its depth level on a second stream for large models
+    depth_order = _depth_order_async(depths) if (not _TILE_LISTS and C * N >= _ASYNC_DEPTH_ORDER_MIN) else None
     opac = opacities[None, :].expand(C, N)
     if compensations is not None:
         opac = opac * compensations
@@ -728,9 +791,13 @@ def rasterization(
     tile_height = math.ceil(height / float(tile_size))
     opac = opac.contiguous()
     # compositor lists: only the (Gaussian, tile) pairs that can contribute
-    _, _, flatten_ids, isect_offsets, tile_order = _bin_tiles(
-        means2d, radii, depths, tile_size, tile_width, tile_height, False, True, True, conics=conics,
-        opacities=opac, depth_order=depth_order)
+    if depth_order is None and _TILE_LISTS:
+        flatten_ids, isect_offsets, tile_order = _tile_lists(means2d, radii, depths, conics, opac, tile_size,
+                                                             tile_width, tile_height)
+    else:
+        _, _, flatten_ids, isect_offsets, tile_order = _bin_tiles(
+            means2d, radii, depths, tile_size, tile_width, tile_height, False, True, True, conics=conics,
+            opacities=opac, depth_order=depth_order)
 
     # channels = [rgb or given colours | features | depth]: the compositor gathers from the tensors in place
     parts = []

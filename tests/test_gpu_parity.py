@@ -310,6 +310,45 @@ def test_footprint_tested_lists_drop_only_pairs_that_cannot_contribute(gpu, tile
     assert dropped > 0
 
 
+@pytest.mark.parametrize("tile_size,views,n,w,h", [(16, 1, 1200, 160, 96), (8, 2, 1200, 160, 96), (16, 3, 20000, 640, 400),
+                                                   (16, 1, 60000, 96, 64)])
+def test_tile_lists_without_a_device_sort_equal_the_sorted_lists(gpu, tile_size, views, n, w, h):
+    """pr_tile_lists_count / pr_tile_lists_fill (per-tile counters, unordered emission, one LDS sort per tile) against
+    the two-level device sort on the same footprint-tested pairs: identical offsets and identical lists, including
+    exact depth ties (resolved by ascending flat index), lists longer than the LDS limit (60k Gaussians on 24 tiles:
+    sorted in global memory), and lists sized from a guess."""
+    rd = _rendering()
+    sc = small_scene(n=n, w=w, h=h, views=views, seed=4, lo=0.01, hi=0.35)
+    sc.means[100:200] = sc.means[0:100]
+    a = scene_args(sc, device=gpu)
+    radii, means2d, depths, conics, _ = rd.fully_fused_projection(
+        a["means"], a["quats"], a["scales"], a["viewmats"], a["Ks"], sc.width, sc.height)
+    opac = a["opacities"][None].expand(views, -1).contiguous()
+    tw, th = math.ceil(sc.width / tile_size), math.ceil(sc.height / tile_size)
+    rd._state.history.clear()
+    _, _, flat_s, offs_s = rd._bin_tiles(means2d, radii, depths, tile_size, tw, th, False, True, conics=conics,
+                                         opacities=opac)
+    for call in range(4):      # calls 3 and 4 size the lists from the earlier counts
+        flat_l, offs_l, order = rd._tile_lists(means2d, radii, depths, conics, opac, tile_size, tw, th)
+        assert torch.equal(offs_l, offs_s), f"offsets differ (call {call})"
+        assert torch.equal(flat_l, flat_s), f"lists differ (call {call})"
+    if n == 60000:
+        lengths = torch.diff(torch.cat([offs_s.flatten(), torch.tensor([flat_s.numel()], device=gpu, dtype=torch.int32)]))
+        assert int(lengths.max()) > 4096
+    if order is not None:
+        assert torch.equal(order.long().sort().values, torch.arange(views * tw * th, device=gpu))
+    # an undersized guess: both calls are repeated
+    key = next(k for k in rd._state.history if k[-1] == "lists")
+    rd._state.history[key] = [flat_s.numel() // 3, flat_s.numel() // 3]
+    flat_l, offs_l, _ = rd._tile_lists(means2d, radii, depths, conics, opac, tile_size, tw, th)
+    assert torch.equal(offs_l, offs_s) and torch.equal(flat_l, flat_s)
+    rd._state.history.clear()
+    # nothing visible
+    flat0, offs0, _ = rd._tile_lists(means2d, torch.zeros_like(radii), depths, conics, opac, tile_size, tw, th)
+    assert flat0.numel() == 0 and int(offs0.abs().sum()) == 0
+    rd._state.history.clear()
+
+
 def test_depth_order_is_the_stable_sort_of_the_depth_bits(gpu):
     rd = _rendering()
     g = torch.Generator().manual_seed(0)
