@@ -271,6 +271,16 @@ int pr_mlp_fwd(int64_t n_pixels, const float *feats, const float *alphas, const 
 int pr_mlp_bwd_input(int64_t n_pixels, const float *v_out, const float *alphas, const float *w0, const float *w1,
                      const float *w2, const float *w3, float zero_below, const uint64_t *masks, float *v_feats,
                      void *stream);
+/* Training (the weights need gradients, pogs/pogs.py:153-161 with `nn_projection` in the optimisers,
+ * pogs/pogs_config.py:78-85).  pr_mlp_fwd_train is pr_mlp_fwd that also stores the three hidden activations,
+ * acts[3, n_pixels, 64].  pr_mlp_bwd_full: from v_out and those activations, the gradients of the four weight
+ * matrices, v_weights[4, 64, 64] (torch.nn.Linear.weight layout; zero-filled by the caller, accumulated with float
+ * atomics) and, when v_feats is not NULL, the gradient with respect to feats (overwritten).  Split-bf16 arithmetic. */
+int pr_mlp_fwd_train(int64_t n_pixels, const float *feats, const float *alphas, const float *w0, const float *w1,
+                     const float *w2, const float *w3, float zero_below, float *out, float *acts, void *stream);
+int pr_mlp_bwd_full(int64_t n_pixels, const float *v_out, const float *feats, const float *alphas, const float *acts,
+                    const float *w0, const float *w1, const float *w2, const float *w3, float zero_below,
+                    float *v_feats, float *v_weights, void *stream);
 
 /* ---- densification: grow / prune the Gaussian set after the backward pass ---------------------------------
  * Replaces gsplat 1.4.0's DefaultStrategy (third-party gsplat/strategy/default.py, ops.py) as constructed at

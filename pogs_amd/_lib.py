@@ -53,6 +53,8 @@ SIGNATURES = {
     "pr_mlp_mask_words": (c_size_t, [c_int64]),
     "pr_mlp_fwd": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "pr_mlp_bwd_input": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "pr_mlp_fwd_train": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "pr_mlp_bwd_full": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "pr_densify_accumulate": (c_int, [c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pr_densify_plan_scratch_bytes": (c_size_t, [c_int]),
     "pr_densify_plan": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),

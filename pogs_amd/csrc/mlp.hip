@@ -203,7 +203,7 @@ template <int PT, int WPE, int BLOCK, bool HOIST, bool BF16>
 __global__ void __launch_bounds__(BLOCK, WPE) mlp_fwd_kernel(int64_t P, const float *__restrict__ feats,
                                                         const float *__restrict__ alphas, const Weights W,
                                                         float zero_below, float *__restrict__ out,
-                                                        unsigned *__restrict__ masks) {
+                                                        unsigned *__restrict__ masks, float *__restrict__ acts) {
   extern __shared__ float lds[];
   if (BF16) stage_weights_bf16<false, BLOCK>(lds, W);
   else stage_weights<false, BLOCK>(lds, W);
@@ -254,6 +254,8 @@ __global__ void __launch_bounds__(BLOCK, WPE) mlp_fwd_kernel(int64_t P, const fl
             }
           if (masks) masks[(((grp * PT + pt) * 64 + lane) * 3 + l)] = bits;
         }
+        // training: the hidden activations are kept for the weight gradients (pr_mlp_bwd_full), [3][P][64]
+        if (acts) store_rows<PT>(acts + (int64_t)l * P * DIM, first, P, lane, dst);
       }
     }
     // LAYERS is even: the result is back in `a`
@@ -335,6 +337,141 @@ __global__ void __launch_bounds__(BLOCK, WPE) mlp_bwd_input_kernel(int64_t P, co
   }
 }
 
+// ---- backward with weight gradients (training) ----------------------------------------------------------------
+// dW_l[out][in] = sum over pixels of G_l[out][p] * H_l[in][p]  (H_l: input of layer l, G_l: gradient at its output)
+// reduces over the PIXEL index, which sits on the lanes in the transposed register layout above.  Both factors go
+// through a per-wavefront LDS image [feature][pixel] (bf16 head and residual), from which a lane (feature m, pixel
+// half h) reads its eight consecutive pixels as one 16-byte matrix operand: A = G_l rows, B = H_l rows, 2 x 2 result
+// tiles x 2 k steps x 3 split products per layer and 32-pixel tile.  The four 64 x 64 gradients stay in 256
+// accumulator registers for the whole persistent loop (one wavefront per SIMD) and leave as float atomics at the
+// end.  The chain G_{l-1} = (W_l^T G_l) * [H_l > 0] is the frozen-weight kernel's; H_l comes from the activations the
+// training forward pass stored (H_0 = the normalised input).  Split bf16 throughout (2^-16 per product, gradients are
+// held to 1e-3).
+constexpr int IMG_PITCH = 40;   // 16-bit units per feature row: 32 pixels + 8 of padding (rows 80 bytes apart)
+struct WaveImages {
+  unsigned short gh[DIM * IMG_PITCH], gl[DIM * IMG_PITCH], hh[DIM * IMG_PITCH], hl[DIM * IMG_PITCH];
+};
+
+__device__ __forceinline__ void write_image(unsigned short *hi, unsigned short *lo, const f16v (&t)[1][2], int lane) {
+  const int p = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      unsigned xh, xl;
+      split_pair(t[0][mt][r], t[0][mt][r + 1], xh, xl);
+      const int f = 32 * mt + 8 * (r >> 2) + 4 * h + (r & 3);
+      hi[f * IMG_PITCH + p] = (unsigned short)xh;
+      hi[(f + 1) * IMG_PITCH + p] = (unsigned short)(xh >> 16);
+      lo[f * IMG_PITCH + p] = (unsigned short)xl;
+      lo[(f + 1) * IMG_PITCH + p] = (unsigned short)(xl >> 16);
+    }
+}
+
+__global__ void __launch_bounds__(256, 1) mlp_bwd_full_kernel(int64_t P, const float *__restrict__ v_out,
+                                                             const float *__restrict__ feats,
+                                                             const float *__restrict__ alphas,
+                                                             const float *__restrict__ acts, const Weights W,
+                                                             float zero_below, float *__restrict__ v_feats,
+                                                             float *__restrict__ v_w) {
+  extern __shared__ float lds[];
+  stage_weights_bf16<true, 256>(lds, W);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  WaveImages &I = reinterpret_cast<WaveImages *>(lds + LAYERS * DIM * DIM)[wave];
+  __syncthreads();
+  const int m = lane & 31, kh = lane >> 5;
+  f16v dw[LAYERS][2][2];
+#pragma unroll
+  for (int l = 0; l < LAYERS; ++l)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dw[l][a][b][r] = 0.f;
+  const int64_t n_groups = (P + 31) / 32;
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < n_groups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t first = grp * 32;
+    asm volatile("" ::: "memory");
+    f16v g[1][2], h[1][2], t[1][2];
+    load_rows<1>(v_out, first, P, lane, g);
+    const int64_t pix = first + m;
+    float al = 1.f;
+    if (alphas) al = pix < P ? alphas[pix] : 0.f;
+    const float inv = alphas ? (al > 0.f ? 1.f / fmaxf(al, 1e-6f) : 0.f) : 1.f;
+    if (zero_below > 0.f && al < zero_below)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[0][mt][r] = 0.f;
+#pragma unroll
+    for (int l = LAYERS - 1; l >= 0; --l) {
+      if (l > 0) {
+        load_rows<1>(acts + (int64_t)(l - 1) * P * DIM, first, P, lane, h);
+      } else {
+        load_rows<1>(feats, first, P, lane, h);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h[0][mt][r] *= inv;
+      }
+      write_image(I.gh, I.gl, g, lane);
+      write_image(I.hh, I.hl, h, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf8v ah[2], al2[2], bh[2], bl[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const int at = (32 * x + m) * IMG_PITCH + 16 * ks + 8 * kh;
+          ah[x] = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v *>(&I.gh[at]));
+          al2[x] = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v *>(&I.gl[at]));
+          bh[x] = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v *>(&I.hh[at]));
+          bl[x] = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v *>(&I.hl[at]));
+        }
+#pragma unroll
+        for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+          for (int no = 0; no < 2; ++no) {
+            dw[l][mo][no] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mo], bh[no], dw[l][mo][no], 0, 0, 0);
+            dw[l][mo][no] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al2[mo], bh[no], dw[l][mo][no], 0, 0, 0);
+            dw[l][mo][no] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mo], bl[no], dw[l][mo][no], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the images are rewritten by the next layer
+      __builtin_amdgcn_wave_barrier();
+      if (l > 0 || v_feats) {
+        layer_product_bf16<1>(lds, l, lane, g, t);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) g[0][mt][r] = (l == 0 || h[0][mt][r] > 0.f) ? t[0][mt][r] : 0.f;
+      }
+    }
+    if (v_feats) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[0][mt][r] *= inv;
+      store_rows<1>(v_feats, first, P, lane, g);
+    }
+  }
+  // result tile (mo, no): row = out feature 32 mo + (r&3) + 8 (r>>2) + 4 kh, column = in feature 32 no + m
+#pragma unroll
+  for (int l = 0; l < LAYERS; ++l)
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+      for (int no = 0; no < 2; ++no)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int out = 32 * mo + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          atomic_add_noret(v_w + (l * DIM + out) * DIM + 32 * no + m, dw[l][mo][no][r]);
+        }
+}
+
 struct Variant {
   int pt, wpe, block;
   bool hoist, bf16;
@@ -381,13 +518,13 @@ extern "C" size_t pr_mlp_mask_words(int64_t n_pixels) {
   return (size_t)((n_pixels + 31) / 32) * 64 * 3 / 2;  // 32 bits per (tile, lane, layer)
 }
 
-extern "C" int pr_mlp_fwd(int64_t n_pixels, const float *feats, const float *alphas, const float *w0, const float *w1,
-                          const float *w2, const float *w3, float zero_below, float *out, uint64_t *masks,
-                          void *stream) {
+static int mlp_forward(int64_t n_pixels, const float *feats, const float *alphas, const float *w0, const float *w1,
+                       const float *w2, const float *w3, float zero_below, float *out, uint64_t *masks, float *acts,
+                       void *stream) {
   if (n_pixels < 0) return PR_EINVAL;
   if (n_pixels == 0) return PR_OK;
   if (!feats || !w0 || !w1 || !w2 || !w3 || !out) return PR_EINVAL;
-  if ((((uintptr_t)feats | (uintptr_t)out) & 15) != 0) return PR_EINVAL;
+  if ((((uintptr_t)feats | (uintptr_t)out | (uintptr_t)acts) & 15) != 0) return PR_EINVAL;
   const pr::Weights W = {w0, w1, w2, w3};
   const pr::Variant v = pr::variant();
   hipStream_t st = (hipStream_t)stream;
@@ -395,7 +532,7 @@ extern "C" int pr_mlp_fwd(int64_t n_pixels, const float *feats, const float *alp
 #define PR_MLP_CASE(PT, WPE, BLK, HOIST, BF)                                                                    \
   if (v.pt == PT && v.wpe == WPE && v.block == BLK && v.hoist == HOIST && v.bf16 == BF)                         \
     return pr::launch(pr::mlp_fwd_kernel<PT, WPE, BLK, HOIST, BF>, "pr_mlp_fwd", n_pixels, v, st, feats, alphas, W, \
-                      zero_below, out, m);
+                      zero_below, out, m, acts);
   PR_MLP_CASE(1, 2, 256, false, false)
   PR_MLP_CASE(1, 4, 512, false, false)
   PR_MLP_CASE(2, 2, 256, false, false)
@@ -405,6 +542,41 @@ extern "C" int pr_mlp_fwd(int64_t n_pixels, const float *feats, const float *alp
   PR_MLP_CASE(1, 2, 256, false, true)
 #undef PR_MLP_CASE
   return PR_EUNSUPPORTED;
+}
+
+extern "C" int pr_mlp_fwd(int64_t n_pixels, const float *feats, const float *alphas, const float *w0, const float *w1,
+                          const float *w2, const float *w3, float zero_below, float *out, uint64_t *masks,
+                          void *stream) {
+  return mlp_forward(n_pixels, feats, alphas, w0, w1, w2, w3, zero_below, out, masks, nullptr, stream);
+}
+
+extern "C" int pr_mlp_fwd_train(int64_t n_pixels, const float *feats, const float *alphas, const float *w0,
+                                const float *w1, const float *w2, const float *w3, float zero_below, float *out,
+                                float *acts, void *stream) {
+  if (n_pixels > 0 && !acts) return PR_EINVAL;
+  return mlp_forward(n_pixels, feats, alphas, w0, w1, w2, w3, zero_below, out, nullptr, acts, stream);
+}
+
+extern "C" int pr_mlp_bwd_full(int64_t n_pixels, const float *v_out, const float *feats, const float *alphas,
+                               const float *acts, const float *w0, const float *w1, const float *w2, const float *w3,
+                               float zero_below, float *v_feats, float *v_weights, void *stream) {
+  if (n_pixels < 0) return PR_EINVAL;
+  if (n_pixels == 0) return PR_OK;
+  if (!v_out || !feats || !acts || !w0 || !w1 || !w2 || !w3 || !v_weights) return PR_EINVAL;
+  if ((((uintptr_t)v_out | (uintptr_t)feats | (uintptr_t)acts | (uintptr_t)v_feats) & 15) != 0) return PR_EINVAL;
+  const pr::Weights W = {w0, w1, w2, w3};
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+  }
+  const int64_t groups = (n_pixels + 31) / 32, blocks = (groups + 3) / 4;
+  const size_t lds = pr::LDS_BYTES + 4 * sizeof(pr::WaveImages);
+  PR_HIP(hipFuncSetAttribute((const void *)pr::mlp_bwd_full_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)lds));
+  hipLaunchKernelGGL(pr::mlp_bwd_full_kernel, dim3((unsigned)(blocks < cus ? blocks : cus)), dim3(256), lds,
+                     (hipStream_t)stream, n_pixels, v_out, feats, alphas, acts, W, zero_below, v_feats, v_weights);
+  return pr::check_launch("pr_mlp_bwd_full");
 }
 
 extern "C" int pr_mlp_bwd_input(int64_t n_pixels, const float *v_out, const float *alphas, const float *w0,

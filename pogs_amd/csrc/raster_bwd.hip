@@ -166,6 +166,12 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
   for (int bend = max_last; bend > range_lo; bend -= BS) {
     const int first = max(range_lo, bend - BS);
     unsigned long long todo = stage_batch<CD, true, BS>(L, lane, pre, cs, N, D, ch_off, rx0, ry0, rx1, ry1);
+#ifdef PR_DIAG
+    if (PR_DIAG == 1 && lane == 0) {
+      atomicAdd(&g_diag[6], 1ull);                                         // batches staged
+      atomicAdd(&g_diag[7], (unsigned long long)(bend - first));           // list entries looked at
+    }
+#endif
     {  // the next batch's geometry travels while this one is composited
       const int nend = bend - BS, nfirst = max(range_lo, nend - BS);
       pre = prefetch_batch(lane, nfirst, nend - nfirst, flatten_ids, means2d, conics, opacities);
@@ -208,6 +214,9 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
         slot[j] = __builtin_amdgcn_ballot_w64(active);
         any |= slot[j];
       }
+#ifdef PR_DIAG
+      if (PR_DIAG == 1 && lane == 0) atomicAdd(&g_diag[4], 1ull);   // iterations entered (staged entries walked)
+#endif
       if (any == 0ull) continue;
 #ifdef PR_DIAG
       const unsigned long long tk1 = __builtin_amdgcn_s_memtime();

@@ -14,8 +14,10 @@ load either way.
 
 Gradients: with frozen weights (the tracker, ``pogs/tracking/rigid_group_optimizer.py``, optimises poses
 through the render) the gradient with respect to the features is one more fused kernel that re-uses the ReLU
-signs recorded by the forward.  When a weight needs a gradient the backward re-runs the four layers with
-torch's GEMMs on the device to obtain them.  There is no CPU path.
+signs recorded by the forward.  When a weight needs a gradient (training: ``nn_projection`` is an optimiser group,
+``pogs/pogs_config.py:78-85``) the forward also stores the three hidden activations and ONE backward kernel
+(``pr_mlp_bwd_full``) produces the four weight gradients -- the reduction over pixels as matrix products with both
+factors transposed through LDS -- and the feature gradient.  There is no CPU path and no torch GEMM.
 """
 from __future__ import annotations
 
@@ -62,53 +64,45 @@ class _FusedMLP(torch.autograd.Function):
         ws = [_f32(w) for w in (w0, w1, w2, w3)]
         P = x.shape[0]
         out = torch.empty_like(x)
-        need_grad = any(ctx.needs_input_grad)
         lib = _lib.load()
-        masks = (torch.empty(lib.pr_mlp_mask_words(P), dtype=torch.int64, device=x.device) if need_grad else None)
+        ctx.weights_need_grad = any(ctx.needs_input_grad[3:])
+        masks = acts = None
         with torch.cuda.device(x.device):
-            _call("pr_mlp_fwd", P, _ptr(x), _ptr(al), *[_ptr(w) for w in ws], float(zero_below), _ptr(out),
-                  _ptr(masks), _stream())
+            if ctx.weights_need_grad:
+                # training: the hidden activations are kept for the weight gradients
+                acts = torch.empty(LAYERS - 1, P, DIM, dtype=torch.float32, device=x.device)
+                _call("pr_mlp_fwd_train", P, _ptr(x), _ptr(al), *[_ptr(w) for w in ws], float(zero_below), _ptr(out),
+                      _ptr(acts), _stream())
+            else:
+                if ctx.needs_input_grad[0]:
+                    masks = torch.empty(lib.pr_mlp_mask_words(P), dtype=torch.int64, device=x.device)
+                _call("pr_mlp_fwd", P, _ptr(x), _ptr(al), *[_ptr(w) for w in ws], float(zero_below), _ptr(out),
+                      _ptr(masks), _stream())
         ctx.zero_below = float(zero_below)
         ctx.shape = feats.shape
-        ctx.weights_need_grad = any(ctx.needs_input_grad[3:])
-        ctx.save_for_backward(x if ctx.weights_need_grad else None, al, masks, *ws)
+        ctx.save_for_backward(x if ctx.weights_need_grad else None, al, masks, acts, *ws)
         return out.view(*feats.shape[:-1], DIM)
 
     @staticmethod
     def backward(ctx, v_out):
-        x, al, masks, *ws = ctx.saved_tensors
+        x, al, masks, acts, *ws = ctx.saved_tensors
         g = _f32(v_out).view(-1, DIM)
         P = g.shape[0]
         v_feats = None
         grads_w = [None] * LAYERS
-        if ctx.weights_need_grad:
-            # weight gradients need every layer's input: re-run the layers with the device GEMMs
-            with torch.enable_grad():
-                xin = x.detach().requires_grad_(ctx.needs_input_grad[0])
-                h = xin
-                if al is not None:
-                    h = torch.where(al[:, None] > 0, h / al.clamp(min=1e-6)[:, None], torch.zeros((), device=h.device))
-                leaves = [w.detach().requires_grad_(True) for w in ws]
-                for i, w in enumerate(leaves):
-                    h = h @ w.t()
-                    if i < LAYERS - 1:
-                        h = torch.relu(h)
-                if ctx.zero_below > 0 and al is not None:
-                    g = torch.where(al[:, None] < ctx.zero_below, torch.zeros((), device=g.device), g)
-                wanted = [t for t, need in zip([xin] + leaves, [ctx.needs_input_grad[0]] + list(ctx.needs_input_grad[3:]))
-                          if need]
-                got = list(torch.autograd.grad(h, wanted, g))
-            if ctx.needs_input_grad[0]:
-                v_feats = got.pop(0).view(ctx.shape)
-            for i in range(LAYERS):
-                if ctx.needs_input_grad[3 + i]:
-                    grads_w[i] = got.pop(0)
-        elif ctx.needs_input_grad[0]:
-            v = torch.empty_like(g)
-            with torch.cuda.device(g.device):
+        with torch.cuda.device(g.device):
+            if ctx.weights_need_grad:
+                v_w = torch.zeros(LAYERS, DIM, DIM, dtype=torch.float32, device=g.device)
+                v = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+                _call("pr_mlp_bwd_full", P, _ptr(g), _ptr(x), _ptr(al), _ptr(acts), *[_ptr(w) for w in ws],
+                      ctx.zero_below, _ptr(v), _ptr(v_w), _stream())
+                v_feats = None if v is None else v.view(ctx.shape)
+                grads_w = [v_w[i] if ctx.needs_input_grad[3 + i] else None for i in range(LAYERS)]
+            elif ctx.needs_input_grad[0]:
+                v = torch.empty_like(g)
                 _call("pr_mlp_bwd_input", P, _ptr(g), _ptr(al), *[_ptr(w) for w in ws], ctx.zero_below, _ptr(masks),
                       _ptr(v), _stream())
-            v_feats = v.view(ctx.shape)
+                v_feats = v.view(ctx.shape)
         return (v_feats, None, None, *grads_w)
 
 

@@ -56,11 +56,21 @@ def main():
         t_t = timed(lambda: torch_fwd(x), args.reps)
     t_fb = timed(fused_fwd_bwd, args.reps)
     t_tb = timed(torch_fwd_bwd, args.reps)
+    for p in m.parameters():
+        p.requires_grad_(True)
+
+    def clear():
+        for p in m.parameters():
+            p.grad = None
+
+    t_fw = timed(lambda: (clear(), fused_fwd_bwd()), args.reps)
+    t_tw = timed(lambda: (clear(), torch_fwd_bwd()), args.reps)
     flop = 4 * 64 * 64 * 2 * P
     print(f"pixels {P}")
     print(f"forward        fused {t_f:.3f} ms ({flop / t_f / 1e9:.1f} TFLOP/s, {P * 516 / t_f / 1e6:.0f} GB/s)   "
           f"torch {t_t:.3f} ms   x{t_t / t_f:.2f}")
     print(f"fwd + d/dfeats fused {t_fb:.3f} ms   torch {t_tb:.3f} ms   x{t_tb / t_fb:.2f}")
+    print(f"fwd + d/dfeats + d/dweights (training) fused {t_fw:.3f} ms   torch {t_tw:.3f} ms   x{t_tw / t_fw:.2f}")
 
 
 if __name__ == "__main__":

@@ -24,7 +24,8 @@ step(); torch.cuda.synchronize(); lib.pr_diag_read(out, 1)
 meta = step(); torch.cuda.synchronize(); lib.pr_diag_read(out, 1)
 it, npx, nslots, c_alpha, c_body, nlanes, c_tail, c_wave = [int(x) for x in out[:8]]
 print(json.dumps({"cfg": sys.argv[1:], "I": meta["n_composited_isects"], "contributing_iters": it,
-                  "half_tile_iters (PR_DIAG=1 builds)": c_alpha, "active_px_per_iter": npx / it,
+                  "half_tile_iters (PR_DIAG=1 builds)": c_alpha, "iterations_entered (PR_DIAG=1)": c_body,
+                  "batches_staged (PR_DIAG=1)": c_tail, "list_entries_looked_at (PR_DIAG=1)": c_wave, "active_px_per_iter": npx / it,
                   "active_slots_per_iter": nslots / it, "active_lanes_per_iter": nlanes / it,
                   "cycles_per_contributing_iter": {"record+alpha": c_alpha / it, "contractions+geometry": c_body / it,
                                                    "readback+atomics": c_tail / it},

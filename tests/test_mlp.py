@@ -29,6 +29,23 @@ def _weights(gen, scale=1.0):
     return [((torch.rand(64, 64, generator=gen, dtype=torch.float64) * 2 - 1) / 8 * scale) for _ in range(4)]
 
 
+def _relu_ambiguous(x, al, ws, rel=2e-4):
+    """Pixels where some hidden pre-activation lies within the forward error bound of zero.  The gradient through a
+    ReLU is a step function of its pre-activation, so at such a pixel a float32 / split-bf16 forward pass may take the
+    other branch than the float64 one and the whole pixel's contribution differs by O(1): the gradient tests give
+    those pixels a zero cotangent (for both sides) and compare the rest to 1e-3."""
+    h = x.double()
+    if al is not None:
+        a = al.double()
+        h = torch.where(a > 0, h / a.clamp(min=1e-6), torch.zeros_like(h))
+    amb = torch.zeros(h.shape[0], dtype=torch.bool)
+    for w in ws[:-1]:
+        pre = h @ w.double().t()
+        amb |= (pre.abs() < rel * pre.abs().amax(-1, keepdim=True).clamp(min=1.0)).any(-1)   # error ~ the pixel's own magnitude
+        h = torch.relu(pre)
+    return amb
+
+
 def test_mask_words_and_validation():
     lib = _lib.load()
     assert lib.pr_mlp_mask_words(0) == 0
@@ -122,6 +139,7 @@ def test_backward_parity(P, train_weights, arith):
     al = torch.rand(P, 1, generator=gen)
     al[::5] = 0.0
     v = torch.randn(P, 64, generator=gen)
+    v[_relu_ambiguous(x, al, ws)] = 0.0
 
     xr = x.double().requires_grad_(True)
     wr = [w.double().requires_grad_(train_weights) for w in ws]
@@ -140,3 +158,38 @@ def test_backward_parity(P, train_weights, arith):
             close(a.grad, b.grad)
     else:
         assert all(w.grad is None for w in wg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,with_alpha,cut,input_grad", [(33, True, 0.0, False), (70001, False, 0.0, True),
+                                                         (4096, True, 0.8, True)])
+def test_fused_weight_gradients(P, with_alpha, cut, input_grad):
+    """pr_mlp_fwd_train + pr_mlp_bwd_full: weight gradients (and, optionally, the feature gradient) of the whole
+    module from one backward kernel; partial last tile, no alpha, the eval-mode cut, features without gradient."""
+    from pogs_amd.mlp import feature_mlp
+    gen = torch.Generator().manual_seed(7 + P)
+    ws = [w.float() for w in _weights(gen, scale=3.0)]
+    x = torch.randn(P, 64, generator=gen)
+    al = torch.rand(P, 1, generator=gen) if with_alpha else None
+    if al is not None:
+        al[::7] = 0.0
+    v = torch.randn(P, 64, generator=gen)
+    amb = _relu_ambiguous(x, al, ws)
+    assert amb.float().mean().item() < 0.25
+    v[amb] = 0.0
+    xr = x.double().requires_grad_(input_grad)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    ref = feature_mlp_ref(xr, None if al is None else al.double(), wr, cut)
+    ref.backward(v.double())
+    xg = x.cuda().requires_grad_(input_grad)
+    wg = [w.cuda().requires_grad_(True) for w in ws]
+    out = feature_mlp(xg, None if al is None else al.cuda(), wg, cut)
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 1e-4 * max(ref.abs().max().item(), 1.0)
+    out.backward(v.cuda())
+    for a, b in zip(wg, wr):
+        assert a.grad.shape == (64, 64)
+        assert (a.grad.cpu().double() - b.grad).abs().max().item() <= 1e-3 * b.grad.abs().max().item()
+    if input_grad:
+        assert (xg.grad.cpu().double() - xr.grad).abs().max().item() <= 1e-3 * xr.grad.abs().max().item()
+    else:
+        assert xg.grad is None
