@@ -282,6 +282,31 @@ int pr_mlp_bwd_full(int64_t n_pixels, const float *v_out, const float *feats, co
                     const float *w0, const float *w1, const float *w2, const float *w3, float zero_below,
                     float *v_feats, float *v_weights, void *stream);
 
+/* ---- CLIP / instance heads on the rendered 96-channel feature image --------------------------------------------
+ * Replace the two tiny-cuda-nn CutlassMLP networks of pogs/fields/gaussian_field.py:105-127 (bias-free, ReLU between
+ * layers: 97 -> 256 x 3 -> 512 and 96 -> 256 x 4 -> 128) and the normalisation applied to their outputs at
+ * pogs/fields/gaussian_field.py:184-190,194-204, one dense layer per call.  float32 in and out, split-bf16 products.
+ *
+ * pr_dense_pack: A[m][k] = src[m * stride_m + k * stride_k] (m < M, k < K) -> matrix-operand order, split, into
+ *   `packed` (pr_dense_packed_bytes(M, K) bytes, 16-byte aligned).  Strides (K, 1) pack a Linear.weight as it is
+ *   (forward), strides (1, K_in) with M = K_in, K = N_out pack its transpose (backward data product).
+ * pr_dense_fwd: Y[p][m] = act(sum_k X[p][k] A[m][k]), p < P, m < M; relu != 0: act = max(0, .); mask != NULL: the
+ *   result is zeroed where mask[p][m] <= 0 (backward through the ReLU whose output was `mask`).  X: [P, ldx >= K],
+ *   Y: [P, ldy >= M], mask: [P, ldm >= M]; M, K and the leading dimensions multiples of 4, pointers 16-byte aligned.
+ * pr_dense_wgrad: dW[n][k] += sum_p G[p][n] H[p][k] (float atomics: the caller zero-fills), G: [P, ldg >= N],
+ *   H: [P, ldh >= K], dW: [N, ldw >= K].
+ * pr_l2norm_fwd: out[p] = y[p] / (|y[p]| + eps), norms[p] = |y[p]| (may be NULL); pr_l2norm_bwd its adjoint.
+ *   N a multiple of 4. */
+size_t pr_dense_packed_bytes(int M, int K);
+int pr_dense_pack(int M, int K, const float *src, int64_t stride_m, int64_t stride_k, void *packed, void *stream);
+int pr_dense_fwd(int64_t P, int M, int K, const float *X, int ldx, const void *packed, int relu, const float *mask,
+                 int ldm, float *Y, int ldy, void *stream);
+int pr_dense_wgrad(int64_t P, int N, int K, const float *G, int ldg, const float *H, int ldh, float *dW, int ldw,
+                   void *stream);
+int pr_l2norm_fwd(int64_t P, int N, const float *y, float eps, float *out, float *norms, void *stream);
+int pr_l2norm_bwd(int64_t P, int N, const float *y, const float *norms, float eps, const float *g, float *dy,
+                  void *stream);
+
 /* ---- densification: grow / prune the Gaussian set after the backward pass ---------------------------------
  * Replaces gsplat 1.4.0's DefaultStrategy (third-party gsplat/strategy/default.py, ops.py) as constructed at
  * nerfstudio/models/splatfacto.py:264-281 and driven at pogs/pogs.py:373-379 (step_pre_backward) and

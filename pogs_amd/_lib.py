@@ -55,6 +55,12 @@ SIGNATURES = {
     "pr_mlp_bwd_input": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "pr_mlp_fwd_train": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
     "pr_mlp_bwd_full": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "pr_dense_packed_bytes": (c_size_t, [c_int, c_int]),
+    "pr_dense_pack": (c_int, [c_int, c_int, _P, c_int64, c_int64, _P, _P]),
+    "pr_dense_fwd": (c_int, [c_int64, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
+    "pr_dense_wgrad": (c_int, [c_int64, c_int, c_int, _P, c_int, _P, c_int, _P, c_int, _P]),
+    "pr_l2norm_fwd": (c_int, [c_int64, c_int, _P, c_float, _P, _P, _P]),
+    "pr_l2norm_bwd": (c_int, [c_int64, c_int, _P, _P, c_float, _P, _P, _P]),
     "pr_densify_accumulate": (c_int, [c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "pr_densify_plan_scratch_bytes": (c_size_t, [c_int]),
     "pr_densify_plan": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
