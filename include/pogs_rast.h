@@ -239,6 +239,25 @@ int pr_rigid_bwd(int64_t N, int G, const float *init_p2ws, const float *p_deltas
                  const float *means, const float *quats, const float *v_means_out, const float *v_quats_out,
                  float *v_p_deltas, void *stream);
 
+/* The same transform applied INSIDE the projection, for the tracker's loop (frozen model, pose deltas trainable;
+ * pogs/tracking/rigid_group_optimizer.py:402-479): pr_project_fwd_rigid is pr_project_fwd on the moved Gaussians
+ * without writing them out, except means_world[N,3] (may be NULL) which the view-dependent colours need;
+ * pr_project_bwd_rigid is pr_project_bwd whose mean cotangent -- plus v_means_world[N,3] (may be NULL), the cotangent
+ * that reached means_world from elsewhere -- goes straight on to v_p_deltas[G,7] (zero-filled by the caller,
+ * accumulated).  As in the reference, whose tape holds the moved means only, the moved quaternions pass no gradient
+ * on; the model's own means/quats/scales receive none. */
+int pr_project_fwd_rigid(int C, int N, int G, const float *init_p2ws, const float *p_deltas, const int32_t *labels,
+                         const float *means, const float *quats, const float *scales, const float *viewmats,
+                         const float *Ks, int width, int height, float eps2d, float near_plane, float far_plane,
+                         float radius_clip, int32_t *radii, float *means2d, float *depths, float *conics,
+                         float *compensations, float *means_world, void *stream);
+int pr_project_bwd_rigid(int C, int N, int G, const float *init_p2ws, const float *p_deltas, const int32_t *labels,
+                         const float *means, const float *quats, const float *scales, const float *viewmats,
+                         const float *Ks, int width, int height, float eps2d, const int32_t *radii,
+                         const float *v_means2d, int ld_means2d, const float *v_depths, const float *v_conics,
+                         int ld_conics, const float *v_compensations, const float *v_means_world, float *v_p_deltas,
+                         float *v_viewmats, void *stream);
+
 /* ---- fused Adam over parameter groups (the step between the gradient exchange and the next forward) ------
  * Replaces the per-group torch.optim.Adam(lr, eps=1e-15).step() calls issued through nerfstudio's
  * Optimizers.optimizer_scaler_step_some (nerfstudio/engine/optimizers.py:159-172; trainer.py:494-510 decides

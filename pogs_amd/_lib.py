@@ -69,6 +69,10 @@ SIGNATURES = {
     "pr_densify_split_children": (c_int, [c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pr_adam_max_groups": (c_int, []),
     "pr_adam_step": (c_int, [_P, c_int, _P]),
+    "pr_project_fwd_rigid": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, c_float,
+                                     c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "pr_project_bwd_rigid": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P,
+                                     c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "pr_rigid_fwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pr_rigid_bwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

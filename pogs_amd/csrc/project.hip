@@ -4,9 +4,21 @@
 // (looping over cameras) backward so that per-Gaussian gradients need no atomics; the only
 // reductions over N (camera-matrix and camera-centre gradients) go wave-DPP -> LDS -> one atomic
 // per workgroup and component.
-#include "common.h"
+#include "rigid_math.h"
 
 namespace pr {
+
+// Rigid groups applied on the fly (pr_project_fwd_rigid / pr_project_bwd_rigid): Gaussian n is moved by its group's
+// p2w * delta * inverse(p2w) before it is projected, so the tracker's per-iteration transform
+// (pogs/tracking/rigid_group_optimizer.py:455-479) and its adjoint need no pass over the model of their own.
+struct RigidGroups {
+  int G;
+  const float *init_p2ws, *p_deltas;
+  const int32_t *labels;
+  float *means_world;          // forward: the moved means [N,3] (the view-dependent colours need them), may be null
+  const float *v_means_world;  // backward: a further cotangent of the moved means [N,3], may be null
+  float *v_p_deltas;           // backward: [G,7], accumulated
+};
 
 struct Cam {
   float R[9];
@@ -121,8 +133,9 @@ __device__ __forceinline__ bool project_one(const Cam &cam, const float *p, int 
   return true;
 }
 
+template <bool RIGID>
 __global__ void __launch_bounds__(256) project_fwd_kernel(
-    int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
+    const RigidGroups rigid, int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
     const float *__restrict__ scales, const float *__restrict__ viewmats, const float *__restrict__ Ks, int width,
     int height, float eps2d, float near_plane, float far_plane, float radius_clip, int32_t *__restrict__ radii,
     float *__restrict__ means2d, float *__restrict__ depths, float *__restrict__ conics,
@@ -134,6 +147,21 @@ __global__ void __launch_bounds__(256) project_fwd_kernel(
   float p[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
   float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
   float s[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+  if (RIGID) {
+    const int g = rigid.labels[n];
+    if (g >= 0 && g < rigid.G) {
+      rg::V3 m = {p[0], p[1], p[2]};
+      float4 qm = make_float4(q[0], q[1], q[2], q[3]);
+      rg::transform(rg::load_pose(rigid.init_p2ws, g), rg::load_pose(rigid.p_deltas, g), m, qm);
+      p[0] = m.x, p[1] = m.y, p[2] = m.z;
+      q[0] = qm.x, q[1] = qm.y, q[2] = qm.z, q[3] = qm.w;
+    }
+    if (c == 0 && rigid.means_world) {
+      rigid.means_world[3 * n] = p[0];
+      rigid.means_world[3 * n + 1] = p[1];
+      rigid.means_world[3 * n + 2] = p[2];
+    }
+  }
   Proj P;
   quat_scale_to_covar(q, s, P);
   int radius = 0;
@@ -183,20 +211,37 @@ __device__ __forceinline__ void block_atomic_add(float v, float *dst, float *lds
   }
 }
 
+template <bool RIGID>
 __global__ void __launch_bounds__(256) project_bwd_kernel(
-    int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
+    const RigidGroups rigid, int C, int N, const float *__restrict__ means, const float *__restrict__ quats,
     const float *__restrict__ scales, const float *__restrict__ viewmats, const float *__restrict__ Ks, int width,
     int height, float eps2d, const int32_t *__restrict__ radii, const float *__restrict__ v_means2d, int ld_m,
     const float *__restrict__ v_depths, const float *__restrict__ v_conics, int ld_c,
     const float *__restrict__ v_comps, float *__restrict__ v_means, float *__restrict__ v_quats,
     float *__restrict__ v_scales, float *__restrict__ v_viewmats) {
   __shared__ float red[4];
+  __shared__ float acc[RIGID ? rg::LDS_GROUPS * 7 : 1];
+  if (RIGID) rg::zero_groups<256>(acc, rigid.G);
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = n < N;
   int nn = live ? n : 0;
   float p[3] = {means[3 * nn], means[3 * nn + 1], means[3 * nn + 2]};
   float q[4] = {quats[4 * nn], quats[4 * nn + 1], quats[4 * nn + 2], quats[4 * nn + 3]};
   float s[3] = {scales[3 * nn], scales[3 * nn + 1], scales[3 * nn + 2]};
+  const rg::V3 m_model = {p[0], p[1], p[2]};
+  int group = -1;
+  if (RIGID) {
+    group = live ? rigid.labels[nn] : -1;
+    if (group >= 0 && group < rigid.G) {
+      rg::V3 m = m_model;
+      float4 qm = make_float4(q[0], q[1], q[2], q[3]);
+      rg::transform(rg::load_pose(rigid.init_p2ws, group), rg::load_pose(rigid.p_deltas, group), m, qm);
+      p[0] = m.x, p[1] = m.y, p[2] = m.z;
+      q[0] = qm.x, q[1] = qm.y, q[2] = qm.z, q[3] = qm.w;
+    } else {
+      group = -1;
+    }
+  }
   Proj P;
   quat_scale_to_covar(q, s, P);
   float vp[3] = {0.f, 0.f, 0.f};
@@ -317,6 +362,25 @@ __global__ void __launch_bounds__(256) project_bwd_kernel(
         block_atomic_add(vt[i], dst + 4 * i + 3, red);
       }
     }
+  }
+  if (RIGID) {
+    // The model is frozen on this path: the cotangent of the moved mean goes straight on to the group's pose delta
+    // (the moved quaternion passes no gradient on, as in the reference, whose tape holds the moved means only).
+    float out[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool valid = group >= 0;
+    if (valid) {
+      rg::V3 gm = {vp[0], vp[1], vp[2]};
+      if (rigid.v_means_world) {
+        gm.x += rigid.v_means_world[3 * nn];
+        gm.y += rigid.v_means_world[3 * nn + 1];
+        gm.z += rigid.v_means_world[3 * nn + 2];
+      }
+      rg::adjoint(rg::load_pose(rigid.init_p2ws, group), rg::load_pose(rigid.p_deltas, group), m_model, gm, nullptr,
+                  nullptr, out);
+    }
+    rg::reduce_to_groups(valid, group, out, acc, rigid.v_p_deltas);
+    rg::flush_groups<256>(acc, rigid.G, rigid.v_p_deltas);
+    return;
   }
   if (!live) return;
   // S = M M^T, M = Rq diag(s):  v_M = 2 v_S M
@@ -620,10 +684,31 @@ extern "C" int pr_project_fwd(int C, int N, const float *means, const float *qua
   int64_t total = (int64_t)C * N;
   if (total > (int64_t)2147483647) return PR_EUNSUPPORTED;
   unsigned grid = (unsigned)((total + 255) / 256);
-  hipLaunchKernelGGL(project_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, means, quats, scales,
-                     viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, radii, means2d, depths,
-                     conics, compensations);
+  hipLaunchKernelGGL(project_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, RigidGroups{}, C, N,
+                     means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
+                     radii, means2d, depths, conics, compensations);
   return check_launch("project_fwd_kernel");
+}
+
+extern "C" int pr_project_fwd_rigid(int C, int N, int G, const float *init_p2ws, const float *p_deltas,
+                                    const int32_t *labels, const float *means, const float *quats,
+                                    const float *scales, const float *viewmats, const float *Ks, int width, int height,
+                                    float eps2d, float near_plane, float far_plane, float radius_clip, int32_t *radii,
+                                    float *means2d, float *depths, float *conics, float *compensations,
+                                    float *means_world, void *stream) {
+  if (C < 0 || N < 0 || G < 0 || width <= 0 || height <= 0) return PR_EINVAL;
+  if ((int64_t)C * N == 0) return PR_OK;
+  if (!means || !quats || !scales || !viewmats || !Ks || !radii || !means2d || !depths || !conics || !labels)
+    return PR_EINVAL;
+  if (G > 0 && (!init_p2ws || !p_deltas)) return PR_EINVAL;
+  int64_t total = (int64_t)C * N;
+  if (total > (int64_t)2147483647) return PR_EUNSUPPORTED;
+  const RigidGroups rigid = {G, init_p2ws, p_deltas, labels, means_world, nullptr, nullptr};
+  unsigned grid = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(project_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rigid, C, N, means, quats,
+                     scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, radii, means2d,
+                     depths, conics, compensations);
+  return check_launch("pr_project_fwd_rigid");
 }
 
 extern "C" int pr_project_bwd(int C, int N, const float *means, const float *quats, const float *scales,
@@ -637,10 +722,30 @@ extern "C" int pr_project_bwd(int C, int N, const float *means, const float *qua
       !v_quats || !v_scales)
     return PR_EINVAL;
   unsigned grid = (unsigned)((N + 255) / 256);
-  hipLaunchKernelGGL(project_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, C, N, means, quats, scales,
-                     viewmats, Ks, width, height, eps2d, radii, v_means2d, ld_means2d, v_depths, v_conics, ld_conics,
-                     v_compensations, v_means, v_quats, v_scales, v_viewmats);
+  hipLaunchKernelGGL(project_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, RigidGroups{}, C, N,
+                     means, quats, scales, viewmats, Ks, width, height, eps2d, radii, v_means2d, ld_means2d, v_depths,
+                     v_conics, ld_conics, v_compensations, v_means, v_quats, v_scales, v_viewmats);
   return check_launch("project_bwd_kernel");
+}
+
+extern "C" int pr_project_bwd_rigid(int C, int N, int G, const float *init_p2ws, const float *p_deltas,
+                                    const int32_t *labels, const float *means, const float *quats,
+                                    const float *scales, const float *viewmats, const float *Ks, int width, int height,
+                                    float eps2d, const int32_t *radii, const float *v_means2d, int ld_means2d,
+                                    const float *v_depths, const float *v_conics, int ld_conics,
+                                    const float *v_compensations, const float *v_means_world, float *v_p_deltas,
+                                    float *v_viewmats, void *stream) {
+  if (C < 0 || N < 0 || G < 0 || width <= 0 || height <= 0 || ld_means2d < 2 || ld_conics < 3) return PR_EINVAL;
+  if (N == 0 || G == 0) return PR_OK;
+  if (!means || !quats || !scales || !viewmats || !Ks || !radii || !v_means2d || !v_conics || !labels || !init_p2ws ||
+      !p_deltas || !v_p_deltas)
+    return PR_EINVAL;
+  const RigidGroups rigid = {G, init_p2ws, p_deltas, labels, nullptr, v_means_world, v_p_deltas};
+  unsigned grid = (unsigned)((N + 255) / 256);
+  hipLaunchKernelGGL(project_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, rigid, C, N, means, quats,
+                     scales, viewmats, Ks, width, height, eps2d, radii, v_means2d, ld_means2d, v_depths, v_conics,
+                     ld_conics, v_compensations, nullptr, nullptr, nullptr, v_viewmats);
+  return check_launch("pr_project_bwd_rigid");
 }
 
 extern "C" int pr_sh_fwd(int C, int N, int K, int degree, const float *means, const float *campos,

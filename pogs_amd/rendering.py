@@ -156,6 +156,65 @@ class _Projection(torch.autograd.Function):
                 None, None)
 
 
+class _ProjectionRigid(torch.autograd.Function):
+    """``_Projection`` of a frozen model whose Gaussians are moved, inside the kernel, by their rigid group's
+    ``p2w * delta * inverse(p2w)`` (the tracker's ``apply_to_model``, ``pogs/tracking/utils.py:53-93``); the gradient
+    goes to ``p_deltas`` (and the view matrices) only.  Also returns the moved means, which the view-dependent
+    colours need."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, labels, init_p2ws, p_deltas, viewmats, Ks, width, height, eps2d, near_plane,
+                far_plane, radius_clip, calc_compensations):
+        C, N, G = viewmats.shape[0], means.shape[0], p_deltas.shape[0]
+        means, quats, scales = means.contiguous(), quats.contiguous(), scales.contiguous()
+        labels, init_p2ws, p_deltas = labels.contiguous(), init_p2ws.contiguous(), p_deltas.contiguous()
+        viewmats, Ks = viewmats.contiguous(), Ks.contiguous()
+        dev = means.device
+        radii = torch.empty(C, N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(C, N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(C, N, dtype=torch.float32, device=dev)
+        conics = torch.empty(C, N, 3, dtype=torch.float32, device=dev)
+        comps = torch.empty(C, N, dtype=torch.float32, device=dev) if calc_compensations else None
+        means_world = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _call("pr_project_fwd_rigid", C, N, G, _ptr(init_p2ws), _ptr(p_deltas), _ptr(labels), _ptr(means),
+                  _ptr(quats), _ptr(scales), _ptr(viewmats), _ptr(Ks), width, height, eps2d, near_plane, far_plane,
+                  radius_clip, _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(comps), _ptr(means_world),
+                  _stream())
+        ctx.save_for_backward(means, quats, scales, labels, init_p2ws, p_deltas, viewmats, Ks, radii)
+        ctx.args = (width, height, eps2d)
+        ctx.mark_non_differentiable(radii)
+        return radii, means2d, depths, conics, comps, means_world
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, v_means_world):
+        means, quats, scales, labels, init_p2ws, p_deltas, viewmats, Ks, radii = ctx.saved_tensors
+        if any(ctx.needs_input_grad[:3]):
+            raise NotImplementedError("rigid= renders a frozen model: means, quats and scales receive no gradient "
+                                      "(use pogs_amd.tracking.apply_to_model + rasterization to train the model too)")
+        width, height, eps2d = ctx.args
+        C, N = radii.shape
+        dev = means.device
+        if v_means2d is None:
+            v_means2d = torch.zeros(C, N, 2, dtype=torch.float32, device=dev)
+        if v_conics is None:
+            v_conics = torch.zeros(C, N, 3, dtype=torch.float32, device=dev)
+        v_means2d, ld_m = _rows(v_means2d, 2)
+        v_conics, ld_c = _rows(v_conics, 3)
+        v_depths = None if v_depths is None else v_depths.contiguous()
+        v_comps = None if v_comps is None else v_comps.contiguous()
+        v_means_world = None if v_means_world is None else v_means_world.contiguous()
+        v_p_deltas = torch.zeros_like(p_deltas)
+        v_viewmats = torch.zeros(C, 4, 4, dtype=torch.float32, device=dev) if ctx.needs_input_grad[6] else None
+        with torch.cuda.device(dev):
+            _call("pr_project_bwd_rigid", C, N, p_deltas.shape[0], _ptr(init_p2ws), _ptr(p_deltas), _ptr(labels),
+                  _ptr(means), _ptr(quats), _ptr(scales), _ptr(viewmats), _ptr(Ks), width, height, eps2d, _ptr(radii),
+                  _ptr(v_means2d), ld_m, _ptr(v_depths), _ptr(v_conics), ld_c, _ptr(v_comps), _ptr(v_means_world),
+                  _ptr(v_p_deltas), _ptr(v_viewmats), _stream())
+        return (None, None, None, None, None, v_p_deltas if ctx.needs_input_grad[5] else None, v_viewmats,
+                None, None, None, None, None, None, None, None)
+
+
 class _SphericalHarmonics(torch.autograd.Function):
     """View-dependent colour; stands in for gsplat ``spherical_harmonics`` fused with the caller's
     ``clamp_min(. + 0.5, 0)``."""
@@ -708,6 +767,7 @@ def rasterization(
     backgrounds: Optional[Tensor] = None, render_mode: str = "RGB", sparse_grad: bool = False,
     absgrad: bool = False, rasterize_mode: str = "classic", channel_chunk: int = 32, distributed: bool = False,
     camera_model: str = "pinhole", covars: Optional[Tensor] = None, features: Optional[Tensor] = None,
+    rigid: Optional[Tuple[Tensor, Tensor, Tensor]] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize N 3-D Gaussians to C images; gsplat 1.4.0 ``rasterization`` signature.
 
@@ -715,6 +775,11 @@ def rasterization(
     ``meta`` are always in the non-packed [C,N,...] layout the reference requests with ``packed=False``),
     ``sparse_grad=False``, ``distributed=False``, pinhole cameras, quats+scales (``covars=None``).
     ``channel_chunk`` is accepted for signature compatibility; channel tiling is chosen inside the library.
+
+    Extensions beyond gsplat: ``features`` (see the module docstring) and ``rigid=(group_labels [N] int32,
+    init_p2ws [G,7], p_deltas [G,7])``: the model is frozen and every Gaussian is moved by its group's
+    ``p2w * delta * inverse(p2w)`` inside the projection kernels (the tracker's ``apply_to_model`` without its pass
+    over the model, forward or backward); gradients reach ``p_deltas`` and the view matrices only.
     """
     N = means.shape[0]
     C = viewmats.shape[0]
@@ -748,9 +813,20 @@ def rasterization(
     # are waited for on the device, each right before the first kernel that reads it.
     for t in (means, quats, scales, opacities, viewmats, Ks, backgrounds):
         wait_ready(t)
-    radii, means2d, depths, conics, compensations = fully_fused_projection(
-        means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
-        calc_compensations=(rasterize_mode == "antialiased"))
+    if rigid is None:
+        radii, means2d, depths, conics, compensations = fully_fused_projection(
+            means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
+            calc_compensations=(rasterize_mode == "antialiased"))
+    else:
+        labels, init_p2ws, p_deltas = rigid
+        G = p_deltas.shape[0]
+        assert labels.shape == (N,) and labels.dtype == torch.int32, (labels.shape, labels.dtype)
+        assert init_p2ws.shape == (G, 7) and p_deltas.shape == (G, 7), (init_p2ws.shape, p_deltas.shape)
+        _check_device(init_p2ws, p_deltas)
+        # `means` from here on: the moved means (what the view directions of the colours are taken from)
+        radii, means2d, depths, conics, compensations, means = _ProjectionRigid.apply(
+            means.detach(), quats.detach(), scales.detach(), labels, init_p2ws, p_deltas, viewmats, Ks, width, height,
+            float(eps2d), float(near_plane), float(far_plane), float(radius_clip), rasterize_mode == "antialiased")
     # the two-level device sort runs its depth level on a second stream for large models
     depth_order = _depth_order_async(depths) if (not _TILE_LISTS and C * N >= _ASYNC_DEPTH_ORDER_MIN) else None
     opac = opacities[None, :].expand(C, N)

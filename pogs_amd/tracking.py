@@ -105,7 +105,7 @@ class TrackingLoop:
     def __init__(self, means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, sh: Tensor, features: Tensor,
                  group_labels: Tensor, n_groups: int, viewmat: Tensor, K: Tensor, width: int, height: int, mlp=None,
                  pose_lr: float = 0.004, pose_lr_final: float = 0.0008, depth_loss_mult: float = 3.7,
-                 dataset_scale: float = 1.0):
+                 dataset_scale: float = 1.0, fused_transform: bool = True):
         from .mlp import FeatureMLP
 
         dev = means.device
@@ -120,6 +120,9 @@ class TrackingLoop:
         self.net.train()        # no alpha cut inside the optimisation
         self.pose_lr, self.pose_lr_final = pose_lr, pose_lr_final
         self.depth_loss_mult, self.dataset_scale = depth_loss_mult, dataset_scale
+        # True: the group transform runs inside the projection kernels (rasterization(rigid=...)); False: as its own
+        # pass over the model (apply_to_model), the reference's structure.  Same results either way.
+        self.fused_transform = fused_transform
         # part-to-world poses: identity rotation at each group's centroid (rigid_group_optimizer.py:108-118)
         self.init_p2w = torch.zeros(n_groups, 7, device=dev)
         self.init_p2w[:, 3] = 1.0
@@ -161,8 +164,12 @@ class TrackingLoop:
         """-> (features after the channel MLP [1,H,W,64], expected depth [1,H,W,1], rgb [1,H,W,3])."""
         from .rendering import rasterization
 
-        m, q = apply_to_model(self.init_p2w, deltas, self.labels, self.means, self.quats)
         common = dict(viewmats=self.viewmat, Ks=self.K, width=self.width, height=self.height, packed=False)
+        if self.fused_transform:
+            m, q = self.means, self.quats
+            common["rigid"] = (self.labels, self.init_p2w, deltas)
+        else:
+            m, q = apply_to_model(self.init_p2w, deltas, self.labels, self.means, self.quats)
         rgbd, _, _ = rasterization(m, q, self.scales, self.opacities, self.sh, sh_degree=3, render_mode="RGB+ED",
                                    tile_size=8, **common)
         f, fa, _ = rasterization(m, q.detach(), self.scales, self.opacities, self.features, **common)

@@ -196,3 +196,66 @@ def test_rigid_entry_points_validate_arguments_without_a_gpu():
         from pogs_amd import tracking
         tracking.apply_to_model(torch.zeros(1, 7), torch.zeros(1, 7), torch.zeros(3, dtype=torch.int32),
                                 torch.zeros(3, 3), torch.zeros(3, 4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("views", [1, 2])
+def test_transform_inside_the_projection_matches_the_two_step_path(views):
+    """rasterization(rigid=...) -- the group transform applied inside pr_project_fwd_rigid / pr_project_bwd_rigid --
+    against apply_to_model followed by rasterization (each half of which has its own oracle test), and against the
+    float64 oracle of both steps: images, and the gradient of a loss on colour, depth and alpha with respect to the
+    pose deltas and the view matrices."""
+    from oracle import gsplat_ref as R
+    from pogs_amd import tracking
+    from pogs_amd.rendering import rasterization
+    from pogs_amd.scenes import make_scene
+
+    n, g, W, H = 3000, 7, 200, 120
+    sc = make_scene(n, W, H, n_features=8, seed=21, n_views=views)
+    gen = torch.Generator().manual_seed(22)
+    labels = torch.randint(-1, g, (n,), generator=gen, dtype=torch.int32)      # -1: not part of any group
+    init = torch.cat([torch.randn(g, 3, generator=gen) * 0.3, torch.nn.functional.normalize(torch.randn(g, 4, generator=gen), dim=-1)], -1)
+    delta = torch.cat([torch.randn(g, 3, generator=gen) * 0.05,
+                       torch.nn.functional.normalize(torch.tensor([[1.0, 0, 0, 0]]) + torch.randn(g, 4, generator=gen) * 0.05, dim=-1)], -1)
+    quats = torch.nn.functional.normalize(sc.quats, dim=-1)
+    wt = torch.randn(views, H, W, 4, generator=gen)
+
+    def run(dev, dtype, raster, fused):
+        cast = lambda t: t.to(dtype).to(dev)
+        d = cast(delta).requires_grad_(True)
+        vm = cast(sc.viewmats).requires_grad_(True)
+        model = dict(scales=cast(sc.log_scales.exp()), opacities=cast(torch.sigmoid(sc.opacity_logits)), colors=cast(sc.sh),
+                     viewmats=vm, Ks=cast(sc.Ks), width=W, height=H, sh_degree=3, render_mode="RGB+ED", packed=False)
+        if fused:
+            out, alpha, meta = raster(means=cast(sc.means), quats=cast(quats), rigid=(labels.to(dev), cast(init), d), **model)
+        else:
+            apply = tracking.apply_to_model if dev != "cpu" else R_apply
+            m, q = apply(cast(init), d, labels.to(dev), cast(sc.means), cast(quats))
+            out, alpha, meta = raster(means=m, quats=q.detach(), **model)
+        ((out * cast(wt)).sum() + alpha.sum()).backward()
+        return out.detach(), alpha.detach(), d.grad, vm.grad, meta
+
+    def R_apply(init_, d_, lab, means_, quats_):      # labels outside [0, g) leave the Gaussian where it is
+        inside = (lab >= 0) & (lab < g)
+        m2, q2 = O.apply_to_model(init_, d_, lab[inside], means_[inside], quats_[inside])
+        m, q = means_.clone(), quats_.clone()
+        m[inside], q[inside] = m2, q2
+        return m, q
+
+    a = run("cuda", torch.float32, rasterization, True)
+    b = run("cuda", torch.float32, rasterization, False)
+    assert torch.equal(a[4]["radii"], b[4]["radii"])
+    # the same arithmetic compiled into two kernels (other fused-multiply-add contractions): last-bit differences in
+    # the moved means, which a pixel on an alpha threshold can amplify -- hence "all but a few pixels to 1e-5"
+    diff = torch.maximum((a[0] - b[0]).abs().amax(-1), (a[1] - b[1]).abs().amax(-1))
+    assert (diff > 1e-5).float().mean().item() <= 1e-3, (diff.max().item(), (diff > 1e-5).float().mean().item())
+    assert_grad_close(a[2], b[2].double().cpu(), "v_p_deltas fused vs two-step")
+    assert_grad_close(a[3][:, :3], b[3][:, :3].double().cpu(), "v_viewmats fused vs two-step")
+    radii = a[4]["radii"].cpu()
+    ref = run("cpu", torch.float64, lambda **kw: R.rasterization(radii_override=radii, **kw), False)
+    amb = ref[4]["ambiguous"]
+    from tests._util import assert_image_close
+    assert_image_close(a[0], ref[0], amb, "fused rigid render")
+    # ambiguous pixels carry their cotangent on one side only: compare gradients when there are none of them
+    if not bool(amb.any()):
+        assert_grad_close(a[2], ref[2], "v_p_deltas vs oracle")
