@@ -73,3 +73,20 @@ def assert_image_close(got, ref, ambiguous, name, tol=IMG_TOL):
     if ambiguous.any():
         scale = max(1.0, ref.abs().max().item())
         assert err[ambiguous].max().item() <= 2e-2 * scale, f"{name}: flagged pixel off by more than one splat"
+
+
+def relu_ambiguous(x, al, ws, rel=2e-4):
+    """Pixels where some hidden pre-activation lies within the forward error bound of zero.  The gradient through a
+    ReLU is a step function of its pre-activation, so at such a pixel a float32 / split-bf16 forward pass may take the
+    other branch than the float64 one and the whole pixel's contribution differs by O(1): the gradient tests give
+    those pixels a zero cotangent (for both sides) and compare the rest to 1e-3."""
+    h = x.double()
+    if al is not None:
+        a = al.double()
+        h = torch.where(a > 0, h / a.clamp(min=1e-6), torch.zeros_like(h))
+    amb = torch.zeros(h.shape[0], dtype=torch.bool)
+    for w in ws[:-1]:
+        pre = h @ w.double().t()
+        amb |= (pre.abs() < rel * pre.abs().amax(-1, keepdim=True).clamp(min=1.0)).any(-1)   # error ~ the pixel's own magnitude
+        h = torch.relu(pre)
+    return amb

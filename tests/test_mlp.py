@@ -12,6 +12,7 @@ import torch
 
 from oracle.mlp_ref import feature_mlp_ref
 from pogs_amd import _lib
+from tests._util import relu_ambiguous as _relu_ambiguous
 
 
 ARITH = {"f32": ("1", 2e-5), "bf16x3": ("4", 1e-4)}
@@ -27,23 +28,6 @@ def arith(request, tuning):
 def _weights(gen, scale=1.0):
     # torch.nn.Linear's default init is U(-1/8, 1/8) for 64 inputs; `scale` widens it so that ReLUs see both signs
     return [((torch.rand(64, 64, generator=gen, dtype=torch.float64) * 2 - 1) / 8 * scale) for _ in range(4)]
-
-
-def _relu_ambiguous(x, al, ws, rel=2e-4):
-    """Pixels where some hidden pre-activation lies within the forward error bound of zero.  The gradient through a
-    ReLU is a step function of its pre-activation, so at such a pixel a float32 / split-bf16 forward pass may take the
-    other branch than the float64 one and the whole pixel's contribution differs by O(1): the gradient tests give
-    those pixels a zero cotangent (for both sides) and compare the rest to 1e-3."""
-    h = x.double()
-    if al is not None:
-        a = al.double()
-        h = torch.where(a > 0, h / a.clamp(min=1e-6), torch.zeros_like(h))
-    amb = torch.zeros(h.shape[0], dtype=torch.bool)
-    for w in ws[:-1]:
-        pre = h @ w.double().t()
-        amb |= (pre.abs() < rel * pre.abs().amax(-1, keepdim=True).clamp(min=1.0)).any(-1)   # error ~ the pixel's own magnitude
-        h = torch.relu(pre)
-    return amb
 
 
 def test_mask_words_and_validation():
