@@ -24,6 +24,8 @@
 namespace pr {
 #ifdef PR_DIAG
 __device__ unsigned long long g_diag[8];
+// PR_DIAG == 3: start / end time stamp, hardware id and walked list length of every wavefront (launch timeline)
+__device__ unsigned long long g_wave_trace[4 * 65536];
 #endif
 
 // GEOM: gradients of the 2D means, conics and opacities are wanted (needs the dot product S);  CGRAD: gradients of
@@ -350,6 +352,14 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
     }
   }
 #ifdef PR_DIAG
+  if (lane == 0 && PR_DIAG == 3 && blockIdx.x < 65536) {
+    unsigned long long *t = g_wave_trace + 4 * (size_t)blockIdx.x;
+    t[0] = tk_start;
+    t[1] = __builtin_amdgcn_s_memtime();
+    t[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |   // XCC_ID
+           (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                       // HW_ID
+    t[3] = (unsigned long long)(max_last - range_lo);
+  }
   if (lane == 0 && PR_DIAG == 2) {
     atomicAdd(&g_diag[0], dg_iters);
     atomicAdd(&g_diag[3], dg_alpha);
@@ -909,6 +919,12 @@ static int launch_bwd_full_mfma(int C, int N, int D, const float *means2d, const
 }
 
 #ifdef PR_DIAG
+extern "C" int pr_diag_trace_read(unsigned long long *out, int n_waves) {
+  if (n_waves > 65536) n_waves = 65536;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pr::g_wave_trace), sizeof(unsigned long long) * 4 * n_waves) != hipSuccess)
+    return -4;
+  return 0;
+}
 extern "C" int pr_diag_read(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pr::g_diag), sizeof(pr::g_diag)) != hipSuccess) return -4;
   if (reset) {
