@@ -5,8 +5,12 @@
 
 namespace pr {
 
+// Wavefronts per SIMD the register allocation is held to: the 2-pixel-per-lane kernel at 33..36 channels lands one
+// register above the 128 that four wavefronts per SIMD allow unless it is told to stay below.
+constexpr int fwd_waves_per_simd(int ppl, int cd) { return (ppl == 2 && cd > 32 && cd <= 36) ? 4 : 1; }
+
 template <int TS, int PPL, int CD>
-__global__ void __launch_bounds__(64 * WPB) raster_fwd_kernel(
+__global__ void __launch_bounds__(64 * WPB, fwd_waves_per_simd(PPL, CD)) raster_fwd_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
     const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
