@@ -376,19 +376,21 @@ def main():
         # counts the (tile, Gaussian) iterations that pass the kernel's "does any pixel take this Gaussian" test and
         # how many of them run over half the tile only; every such iteration evaluates all pixels of the (half) tile.
         fp32 = None
+        fwd_plan = _lib.raster_plan(D, ts, n_tiles)
+        bwd_plan = _lib.raster_plan(D, ts, n_tiles, backward=True)
         diag = pair_counts(f"{N}x{W}x{H}xF{F}ts{ts}")
         if dom == "pr_raster_bwd" and diag:
             iters, half = diag["contributing_iters"], diag["half_tile_iters"]
-            pairs = (iters - half) * ts * ts + half * ts * ts / 2
+            region = ts * ts * diag.get("pixels_per_lane", 4) // 4     # pixels one wavefront covers
+            assert diag.get("pixels_per_lane", 4) == bwd_plan[0], "pair counts were taken with another kernel variant"
+            pairs = (iters - half) * region + half * region / 2
             fma = 2 * D + 30
             flops = 2.0 * fma * pairs
-            fp32 = {"fma_per_pixel_pair": fma, "tile_gaussian_iterations": iters, "of_them_half_tile": half,
+            fp32 = {"fma_per_pixel_pair": fma, "tile_gaussian_iterations": iters, "of_them_half_tile": half, "pixels_per_iteration": region,
                     "pixel_pairs_evaluated": pairs, "pixel_pairs_contributing": diag["active_px_per_iter"] * iters,
                     "achieved_tflops": flops / (avg_ms * 1e-3) / 1e12, "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
                     "frac": flops / (avg_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                     "source": "profiles/r02_bwd_pair_counts.json (diagnostic build, view 0)"}
-        fwd_plan = _lib.raster_plan(D, ts, n_tiles)
-        bwd_plan = _lib.raster_plan(D, ts, n_tiles, backward=True)
         out = {
             "metric": ("Mpix/s fwd+bwd (1M Gauss, 1080p, RGB+32ch feat)" if args.config == "cfg2" and not (
                 args.gaussians or args.width or args.height or args.features is not None or args.tile_size)

@@ -31,8 +31,15 @@ __device__ unsigned long long g_wave_trace[4 * 65536];
 // GEOM: gradients of the 2D means, conics and opacities are wanted (needs the dot product S);  CGRAD: gradients of
 // the colours are wanted.  A caller that optimises poses through frozen appearance (the tracker) asks for GEOM only:
 // the per-channel accumulation, its folds and its read-back -- most of the per-Gaussian work -- are compiled out.
+#ifndef BWD_FORCE_WAVES
+#define BWD_FORCE_WAVES 1
+#endif
+constexpr int bwd_waves_per_simd(int ppl, int cd, bool geom, bool cgrad) {
+  return (ppl == 2 && cd > 32 && cd <= 36 && geom && cgrad) ? BWD_FORCE_WAVES : 1;
+}
+
 template <int TS, int PPL, int CD, bool GEOM, bool CGRAD>
-__global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
+__global__ void __launch_bounds__(64 * WPB, bwd_waves_per_simd(PPL, CD, GEOM, CGRAD)) raster_bwd_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
     const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
@@ -960,7 +967,11 @@ static BwdPlan plan_bwd(int D, int geom_grad, bool color_grad, int tile_size, in
     return p;
   }
   const int cd = pick_chunk(p.per);
-  p.ppl = cd <= 36 ? 4 : cd <= 72 ? 2 : 1;
+  // One wavefront per 16x16 tile (4 pixels per lane) amortises the per-Gaussian work best, but its jobs are long: with
+  // ~8k tiles a launch is four rounds of jobs per wavefront slot and the last one runs half empty.  Measured at 36
+  // channels, 1M-3M Gaussians: 1080p (8160 tiles) 1.16-1.53 ms at 2 pixels per lane against 1.19-1.60 at 4; 4K (32400
+  // tiles) 3.89 against 3.60.
+  p.ppl = cd <= 36 ? (n_tiles_total >= 16384 ? 4 : 2) : cd <= 72 ? 2 : 1;
   // without colour gradients the per-Gaussian folds are few and the registers of two pixels per lane allow three
   // wavefronts per SIMD: measured 0.74 ms against 0.81 ms at 36 channels, 1M Gaussians, 1080p
   if (!color_grad && p.ppl == 4) p.ppl = 2;

@@ -472,11 +472,11 @@ static FwdPlan plan_fwd(int D, int tile_size, int64_t n_tiles_total) {
     return p;
   }
   const int cd = pick_chunk(p.per);
-  // Narrow chunks: 4 pixels per lane (few registers either way).  From 25 channels on, 2 pixels per lane: half
-  // the accumulators -> <= 128 registers -> three to four wavefronts per SIMD instead of two, which matters
-  // more than the per-Gaussian work a second wavefront per tile repeats (a wavefront issues at most one
-  // vector instruction every four cycles, the SIMD takes one every two): 0.52 vs 0.57 ms at 36 channels.
-  p.ppl = cd <= 24 ? 4 : cd <= 72 ? 2 : 1;
+  // 2 pixels per lane up to 72 channels: half the accumulators of 4 pixels per lane (<= 128 registers up to 36 channels:
+  // four wavefronts per SIMD) and twice as many, shorter jobs, which matters more than the per-Gaussian work a second
+  // wavefront per tile repeats.  Measured at 1M Gaussians, 1080p: 0.19 / 0.30 / 0.47 ms at 4 / 16 / 36 channels against
+  // 0.24 / 0.34 / 0.53 at 4 pixels per lane and 0.21 / 0.34 / 0.54 at 1; the same order at 200k / 720p and 3M / 4K.
+  p.ppl = cd <= 72 ? 2 : 1;
   while (p.ppl > 1 && n_tiles_total * (4 / p.ppl) < 3072) p.ppl >>= 1;
   const int forced = tuning().fwd_ppl;
   if (forced == 1 || (forced == 2 && cd <= 72) || (forced == 4 && cd <= 48)) p.ppl = forced;

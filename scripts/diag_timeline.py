@@ -20,7 +20,9 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-n_waves = ((w + ts - 1) // ts) * ((h + ts - 1) // ts)
+n_tiles = ((w + ts - 1) // ts) * ((h + ts - 1) // ts)
+ppl = _lib.raster_plan(3 + f + 1, ts, n_tiles, backward=True)[0]
+n_waves = n_tiles * (4 // ppl if ts == 16 else 1)
 buf = (ctypes.c_ulonglong * (4 * n_waves))()
 assert lib.pr_diag_trace_read(buf, n_waves) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(n_waves, 4).astype(np.int64)
@@ -34,7 +36,7 @@ for x in np.unique(xcc):
     rel_start[m] -= start[m].min()
     rel_end[m] -= start[m].min()
 span = rel_end.max()
-out = {"waves": int(n_waves), "span_ticks": int(span), "mean_dur": float(dur.mean()), "max_dur": int(dur.max()),
+out = {"pixels_per_lane": ppl, "waves": int(n_waves), "span_ticks": int(span), "mean_dur": float(dur.mean()), "max_dur": int(dur.max()),
        "mean_resident_waves": float(dur.sum() / span), "list_len_mean": float(length.mean()), "list_len_max": int(length.max())}
 bins = 25
 occ = []
