@@ -60,7 +60,8 @@ __global__ void __launch_bounds__(64 * WPB, bwd_waves_per_simd(PPL, CD, GEOM, CG
   constexpr int NV = CDR + (GEOM ? 8 : 0);    // values reduced per Gaussian
   static_assert(GEOM || CGRAD, "nothing to compute");
   // 1 pixel per lane: 16-entry batches keep the slice (colours + reduction area) under 10 KB = 4 wavefronts/SIMD
-  constexpr int BS = PPL == 1 ? 16 : batch_size(PPL);
+  // 2 pixels per lane: 64-entry batches while the slice stays under 15 KB (three wavefronts per SIMD), else 32
+  constexpr int BS = PPL == 1 ? 16 : (PPL == 2 && CD <= 36) ? WAVE : batch_size(PPL);
   __shared__ WaveLds<CD, true, BS> lds[WPB];
   static_assert(WPB == 1, "one wavefront per workgroup");
   const int lane = threadIdx.x & 63;
@@ -317,6 +318,11 @@ __global__ void __launch_bounds__(64 * WPB, bwd_waves_per_simd(PPL, CD, GEOM, CG
       if (PPL == 4 && HALF_SKIP && (slot[2 % PPL] | slot[3 % PPL]) == 0ull)
         composite(integral_constant<int, 0>{}, integral_constant<int, PPL / 2>{});
       else if (PPL == 4 && HALF_SKIP && (slot[0] | slot[1 % PPL]) == 0ull)
+        composite(integral_constant<int, PPL / 2>{}, integral_constant<int, PPL>{});
+      // two pixels per lane: 24 % of the contributing iterations touch one of the two 16x4 strips only (-1.4 % kernel time)
+      else if (PPL == 2 && HALF_SKIP && slot[1 % PPL] == 0ull)
+        composite(integral_constant<int, 0>{}, integral_constant<int, (PPL + 1) / 2>{});
+      else if (PPL == 2 && HALF_SKIP && slot[0] == 0ull)
         composite(integral_constant<int, PPL / 2>{}, integral_constant<int, PPL>{});
       else
         composite(integral_constant<int, 0>{}, integral_constant<int, PPL>{});
