@@ -311,7 +311,10 @@ def main():
     # going for about half a second so that clocks, caches and the intersection-count history are in steady state
     t_setup = time.perf_counter()
     n_setup = 0
-    while n_setup < n_views or (time.perf_counter() - t_setup < args.precondition_s and n_setup < 1000):
+    # (with more than one rank every step is a collective: the count must not depend on a local clock)
+    fixed = max(n_views, 48) if world > 1 else None
+    while (n_setup < fixed) if fixed is not None else (
+            n_setup < n_views or (time.perf_counter() - t_setup < args.precondition_s and n_setup < 1000)):
         step()
         n_setup += 1
         if n_setup % 8 == 0:
@@ -341,6 +344,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the table of every stage: a separate pass after the timed region -- run by EVERY rank (with more than one rank a
+    # step contains collectives), only rank 0 records
+    full = rendering.StageTimer()
+    if rank == 0:
+        rendering.set_stage_timer(full)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    rendering.set_stage_timer(None)
+    if world > 1:
+        if grads is not None:
+            grads.wait_all()
+        torch.cuda.synchronize()
+        dist.barrier()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         pixels = world * H * W
@@ -355,12 +373,6 @@ def main():
         per_stage, total_bytes = stage_bytes(N, 1, I_walked, H * W, 16, F, D, key_bits)
         per_stage_gsplat, total_gsplat = stage_bytes(N, 1, I_gsplat, H * W, 16, F, D, key_bits)
         summ = timer.summary()
-        full = rendering.StageTimer()
-        rendering.set_stage_timer(full)
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        rendering.set_stage_timer(None)
         stages = {k: v[1] / max(v[0], 1) * (v[0] / args.steps) for k, v in full.summary().items()}  # ms per step
         stages.update({k: v[1] / max(v[0], 1) * (v[0] / args.steps) for k, v in summ.items()})
         # the dominant kernel: the slower of the two compositing entry points (the ones timed inside the timed region)
