@@ -31,15 +31,8 @@ __device__ unsigned long long g_wave_trace[4 * 65536];
 // GEOM: gradients of the 2D means, conics and opacities are wanted (needs the dot product S);  CGRAD: gradients of
 // the colours are wanted.  A caller that optimises poses through frozen appearance (the tracker) asks for GEOM only:
 // the per-channel accumulation, its folds and its read-back -- most of the per-Gaussian work -- are compiled out.
-#ifndef BWD_FORCE_WAVES
-#define BWD_FORCE_WAVES 1
-#endif
-constexpr int bwd_waves_per_simd(int ppl, int cd, bool geom, bool cgrad) {
-  return (ppl == 2 && cd > 32 && cd <= 36 && geom && cgrad) ? BWD_FORCE_WAVES : 1;
-}
-
 template <int TS, int PPL, int CD, bool GEOM, bool CGRAD>
-__global__ void __launch_bounds__(64 * WPB, bwd_waves_per_simd(PPL, CD, GEOM, CGRAD)) raster_bwd_kernel(
+__global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
     int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
     const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
