@@ -69,7 +69,8 @@ def assert_image_close(got, ref, ambiguous, name, tol=IMG_TOL):
     worst = err[clean].max().item() if clean.any() else 0.0
     assert worst <= tol, f"{name}: max abs err {worst:.3e} > {tol} on unflagged pixels"
     frac = ambiguous.float().mean().item()
-    assert frac <= 0.02, f"{name}: {frac:.3%} of pixels flagged ambiguous"
+    # at most 2 % of the pixels may be flagged -- or 8 pixels: in a 16x16 image every pixel is 0.4 %
+    assert frac <= max(0.02, 8.0 / ambiguous.numel()), f"{name}: {frac:.3%} of pixels flagged ambiguous"
     if ambiguous.any():
         scale = max(1.0, ref.abs().max().item())
         assert err[ambiguous].max().item() <= 2e-2 * scale, f"{name}: flagged pixel off by more than one splat"
