@@ -2,7 +2,7 @@
 """Headline benchmark: Mpix/s of one rasterization forward+backward at the POGS training-step shape
 (1M Gaussians, 1920x1080, SH-RGB + expected depth + 32 feature channels) on MI355X.
 
-  python bench.py --gpus 1 --steps K --warmup W [--config cfg2|cfg1|cfg5|cfg3]
+  python bench.py --gpus 1 --steps K --warmup W [--config cfg2|cfg1|cfg4|cfg5|cfg3]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one `rasterization()` call forward + backward (projection, SH, binning + sort, compositing and
@@ -41,6 +41,7 @@ CONFIGS = {
     # name: (gaussians, width, height, feature channels, tile size)
     "cfg1": (10_000, 256, 256, 16, 16),
     "cfg2": (1_000_000, 1920, 1080, 32, 16),
+    "cfg4": (3_000_000, 1920, 1080, 32, 16),     # multi-view training: 8 ring cameras, one view per GPU and step
     "cfg5": (6_000_000, 3840, 2160, 64, 16),
 }
 

@@ -1,23 +1,26 @@
 """Size-independent properties at the full sizes of the secondary workload shapes (the oracle cannot finish these in
 seconds): the 4K stress shape (6M Gaussians, 3840x2160, RGB+ED + 64 feature channels = 68 composited channels,
-32,400 tiles -> 15 tile bits) forward + backward, and the tracker's 50-iteration pose loop at 200k Gaussians,
-640x360.  ``bench.py --config cfg5`` / ``--config cfg3`` time the same workloads."""
+32,400 tiles -> 15 tile bits) and one GPU's share of the multi-view shape (3M Gaussians, 1080p, 36 channels) forward
++ backward, and the tracker's 50-iteration pose loop at 200k Gaussians, 640x360.  ``bench.py --config cfg5`` /
+``cfg4`` / ``cfg3`` time the same workloads."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 
-def test_stress_shape_properties_forward_and_backward(gpu):
+@pytest.mark.parametrize("N,W,H,F,tile_bits", [
+    (6_000_000, 3840, 2160, 64, 15),      # the 4K stress shape: forward in two passes of <= 36 channels, backward 68 at once
+    (3_000_000, 1920, 1080, 32, 13),      # one GPU's share of the 8-camera multi-view shape (bench.py --config cfg4)
+])
+def test_stress_shape_properties_forward_and_backward(gpu, N, W, H, F, tile_bits):
     from pogs_amd import _lib
     from pogs_amd import rendering as rd
     from pogs_amd.scenes import make_scene
 
-    N, W, H, F = 6_000_000, 3840, 2160, 64
     D = 3 + F + 1
-    n_tiles = (W // 16) * (H // 16)
-    assert n_tiles == 32400 and n_tiles.bit_length() == 15
-    # the kernels this shape runs: forward in two passes of <= 36 channels, backward all 68 channels at once
+    n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    assert n_tiles.bit_length() == tile_bits
     assert _lib.raster_plan(D, 16, n_tiles)[:2] == (2, 36)
     assert _lib.raster_plan(D, 16, n_tiles, backward=True)[:2] == (2, D)
     sc = make_scene(N, W, H, n_features=F, seed=0)
@@ -56,10 +59,10 @@ def test_stress_shape_properties_forward_and_backward(gpu):
         lin = (2 * oa - 3 * ob - oc).abs().max().item()
     assert lin <= 1e-3, lin
     del oa, ob, oc, fb, out
-    # gsplat's tables: sorted keys, 15 tile bits, offsets partition them
+    # gsplat's tables: sorted keys, tile ids within their bits, offsets partition them
     ids = meta["isect_ids"]
     assert ids.numel() > N and bool((ids[1:] >= ids[:-1]).all())
-    assert int((ids >> 32).max()) < n_tiles and int(ids.max()) >> (32 + 15) == 0
+    assert int((ids >> 32).max()) < n_tiles and int(ids.max()) >> (32 + tile_bits) == 0
     offs = meta["isect_offsets"].flatten().long()
     assert int(offs[0]) == 0 and bool((offs[1:] >= offs[:-1]).all())
     assert int(meta["tiles_per_gauss"].sum()) == ids.numel()
