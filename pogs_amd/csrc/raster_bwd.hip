@@ -53,8 +53,9 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
   constexpr int NV = CDR + (GEOM ? 8 : 0);    // values reduced per Gaussian
   static_assert(GEOM || CGRAD, "nothing to compute");
   // 1 pixel per lane: 16-entry batches keep the slice (colours + reduction area) under 10 KB = 4 wavefronts/SIMD
-  // 2 pixels per lane: 64-entry batches while the slice stays under 15 KB (three wavefronts per SIMD), else 32
-  constexpr int BS = PPL == 1 ? 16 : (PPL == 2 && CD <= 36) ? WAVE : batch_size(PPL);
+  // 2 pixels per lane, up to 36 channels: 56-entry batches -- the largest whose slice (13 KB) lets twelve wavefronts (the
+  // register limit) share a CU's LDS: 1.165 (32 entries) -> 1.148 (64, eleven wavefronts) -> 1.12 ms; wider passes: 32
+  constexpr int BS = PPL == 1 ? 16 : (PPL == 2 && CD <= 36) ? 56 : batch_size(PPL);
   __shared__ WaveLds<CD, true, BS> lds[WPB];
   static_assert(WPB == 1, "one wavefront per workgroup");
   const int lane = threadIdx.x & 63;

@@ -19,8 +19,9 @@ __global__ void __launch_bounds__(64 * WPB, fwd_waves_per_simd(PPL, CD)) raster_
   using Rg = Region<TS, PPL>;
   constexpr int ROW = color_row(CD);
   constexpr int CDP = round4(CD);
-  // 2 pixels per lane, narrow passes: 64-entry batches (11 KB slice, still 14 wavefronts per CU): 0.475 -> 0.465 ms
-  constexpr int BS = (PPL == 2 && CD <= 36) ? WAVE : batch_size(PPL);
+  // 2 pixels per lane, narrow passes: 56-entry batches -- the largest whose slice (9.6 KB) still lets sixteen wavefronts
+  // share a CU's LDS: 0.475 (32 entries) -> 0.465 (64, fourteen wavefronts) -> 0.454 ms
+  constexpr int BS = (PPL == 2 && CD <= 36) ? 56 : batch_size(PPL);
   __shared__ WaveLds<CD, false, BS> lds[WPB];
   static_assert(WPB == 1, "one wavefront per workgroup");
   const int lane = threadIdx.x & 63;

@@ -36,6 +36,8 @@ def scene_args(sc, dtype=torch.float32, device="cpu", requires_grad=False):
 # (name, worst |got - ref| / |ref| over the elements with |ref| > 1e-3 max|ref|, elements counted): what the
 # comparisons below measured beyond what they assert; tests/conftest.py writes it out at the end of a session.
 REL_ERRORS = []
+# (name, largest error / allowed error) of every gradient and image comparison: how close each came to its bound
+MARGINS = []
 
 
 def assert_grad_close(got, ref, name, rtol=GRAD_RTOL, atol_frac=1e-4):
@@ -54,6 +56,7 @@ def assert_grad_close(got, ref, name, rtol=GRAD_RTOL, atol_frac=1e-4):
     if big.any():
         REL_ERRORS.append((name, float((err[big] / ref.abs()[big]).max()), int(big.sum())))
     bound = rtol * ref.abs() + atol_frac * scale
+    MARGINS.append((name, float((err / bound).max())))
     bad = err > bound
     assert not bad.any(), (
         f"{name}: {int(bad.sum())}/{bad.numel()} elements off; max err {err.max().item():.3e} "
@@ -67,6 +70,7 @@ def assert_image_close(got, ref, ambiguous, name, tol=IMG_TOL):
     err = (got - ref).abs().amax(dim=-1)
     clean = ~ambiguous
     worst = err[clean].max().item() if clean.any() else 0.0
+    MARGINS.append((name, worst / tol))
     assert worst <= tol, f"{name}: max abs err {worst:.3e} > {tol} on unflagged pixels"
     frac = ambiguous.float().mean().item()
     # at most 2 % of the pixels may be flagged -- or 8 pixels: in a 16x16 image every pixel is 0.4 %

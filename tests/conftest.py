@@ -58,4 +58,9 @@ def pytest_sessionfinish(session, exitstatus):
     rec = {"comparisons": len(REL_ERRORS), "worst_relative_error": worst[0][1],
            "median_of_worsts": sorted(r[1] for r in REL_ERRORS)[len(REL_ERRORS) // 2],
            "over_1e-3": sum(1 for r in REL_ERRORS if r[1] > 1e-3), "top": worst[:25]}
+    try:
+        from tests._util import MARGINS
+        rec["closest_to_their_bound (error / allowed)"] = sorted(MARGINS, key=lambda r: -r[1])[:15]
+    except Exception:
+        pass
     json.dump(rec, open(os.path.join(out_dir, "grad_relative_errors.json"), "w"), indent=1)

@@ -244,6 +244,7 @@ def test_two_threads_on_two_streams_render_independently(gpu):
 
     rd._state.history.clear()
     want = [render(a) for a in args]
+    torch.cuda.synchronize()      # the workers' streams do not wait for the stream `want` was rendered on
     assert want[0][2] != want[1][2]
     errors = []
 
