@@ -414,6 +414,7 @@ def rasterization(
     opac = opacities[None, :].expand(C, N)
     if comps is not None:
         opac = opac * comps
+    clamp_ambiguous = None
     if sh_degree is None:
         cols = colors[None].expand(C, -1, -1) if colors.dim() == 2 else colors
     else:
@@ -421,6 +422,9 @@ def rasterization(
         dirs = means[None, :, :] - camtoworlds[:, None, :3, 3]
         shs = colors[None].expand(C, -1, -1, -1) if colors.dim() == 3 else colors
         cols = spherical_harmonics(sh_degree, dirs, shs, masks=radii > 0)
+        # clamp_min(. + 0.5, 0) is a step for the gradient: a colour within float32 resolution of the clamp may fall
+        # either side in a float32 implementation; flagged per (Gaussian, colour channel) for the gradient tests
+        clamp_ambiguous = ((cols.detach() + 0.5).abs() < 1e-6).any(dim=0)
         cols = torch.clamp_min(cols + 0.5, 0.0)
     if features is not None:
         f = features[None].expand(C, -1, -1) if features.dim() == 2 else features
@@ -454,6 +458,6 @@ def rasterization(
         "conics": conics, "opacities": opac, "tile_width": tw, "tile_height": th,
         "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids, "flatten_ids": flatten_ids,
         "isect_offsets": isect_offsets, "width": width, "height": height, "tile_size": tile_size,
-        "n_cameras": C, "ambiguous": ambiguous,
+        "n_cameras": C, "ambiguous": ambiguous, "colour_clamp_ambiguous": clamp_ambiguous,
     }
     return render_colors, render_alphas, meta

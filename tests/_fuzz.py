@@ -99,6 +99,19 @@ def run_cases(cases, seed, dev, large=False, only=-1, log=print, oracle_chunk=32
                 ((ref * vc.double()).sum() + (ralpha * va.double()).sum()).backward()
             else:  # everything culled: the oracle returns constants; the device path must hand back zero gradients
                 assert all(v.grad is None or float(v.grad.abs().max()) == 0.0 for v in leaves_g.values()), "culled grads"
+            ca = rmeta.get("colour_clamp_ambiguous")
+            if ca is not None and bool(ca.any()) and leaves_g["colors"].grad is not None:
+                # a view-dependent colour within float32 resolution of the clamp at zero: that (Gaussian, channel)'s
+                # coefficient gradient is either everything or nothing; so is what reaches the mean through the
+                # view direction
+                keep_c = (~ca)[:, None, :].double()
+                leaves_c["colors"].grad.mul_(keep_c)
+                leaves_g["colors"].grad.mul_(keep_c.float().to(dev))
+                rows = ca.any(dim=-1)
+                for k in ("means",):
+                    if leaves_c[k].grad is not None and leaves_g[k].grad is not None:
+                        leaves_c[k].grad[rows] = 0
+                        leaves_g[k].grad[rows.to(dev)] = 0
             for k in leaves_g:
                 if leaves_c[k].grad is not None and leaves_g[k].requires_grad and (k != "features" or F):
                     # twice the unit-test tolerance: float32 accumulation over up to 97 channels x whole images
