@@ -125,6 +125,12 @@ int pr_isect_emit_sort(int C, int N, const float *means2d, const int32_t *radii,
                        int64_t *isect_ids, int32_t *flatten_ids, int32_t *isect_offsets, int32_t *tile_order,
                        const int64_t *n_isects_dev, const int32_t *depth_order, void *scratch,
                        size_t scratch_bytes, void *stream);
+/* The count of phase 1 for a host that does not want to wait for it: a one-thread kernel stores *count_dev into
+ * host_words[0] and then `sequence` into host_words[1] (page-locked, device-visible host memory; system-scope
+ * stores, the second one a release).  The caller launches phase 2 in capacity mode, then polls host_words[1] for
+ * its sequence number and reads host_words[0].  Takes the place of gsplat's blocking `cum_tiles[-1].item()`
+ * (gsplat/cuda/_wrapper.py `isect_tiles`, csrc isect_tiles) without a copy command or an event on the stream. */
+int pr_publish_count(const int64_t *count_dev, int64_t *host_words, int64_t sequence, void *stream);
 /* The compositor's lists in two calls, without a device-wide sort: what `isect_tiles` + `isect_offset_encode` produce
  * for the pairs that can contribute (conics/opacities required: the footprint-tested rule of pr_isect_count), in the
  * same order (camera, tile, depth bits, flat index), but WITHOUT gsplat's 64-bit keys.

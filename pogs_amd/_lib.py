@@ -39,6 +39,7 @@ SIGNATURES = {
     "pr_tile_lists_count": (c_int, [c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "pr_tile_lists_fill": (c_int, [c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_int64, _P, _P, _P,
                                    _P]),
+    "pr_publish_count": (c_int, [_P, _P, c_int64, _P]),
     "pr_depth_order_scratch_bytes": (c_size_t, [c_int, c_int]),
     "pr_depth_order": (c_int, [c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "pr_depth_order_static_max": (c_int64, []),

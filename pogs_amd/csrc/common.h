@@ -43,7 +43,8 @@ struct Tuning {
   int bwd_ppl;      // POGS_RAST_BWD_PPL: as fwd_ppl for the backward compositor
   int bwd_mfma;     // POGS_RAST_BWD_MFMA: 0 = vector kernels only for the geometry-only backward
   int mlp_variant;  // POGS_MLP_VARIANT: -1 = default
-  int depth_sort;   // POGS_RAST_DEPTH_SORT: 2 = sample sort between 32 K and 1.25 M Gaussians (default: radix sort)
+  int depth_sort;   // POGS_RAST_DEPTH_SORT: 0 = chained-scan radix sort (onesweep.h), 1 = rocPRIM's radix sort for both binning
+                    // sorts, 2 = sample sort of the depth keys between 32 K and 1.25 M Gaussians
 };
 const Tuning &tuning();
 

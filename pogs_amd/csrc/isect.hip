@@ -13,6 +13,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "onesweep.h"
 
 namespace pr {
 
@@ -682,7 +683,8 @@ using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::
                                               rocprim::default_config, 512 * 1024>;
 
 struct Phase2Layout {
-  size_t dkeys_in, dkeys_out, dvals_in, dvals_out, starts, tkeys_in, tkeys_out, tvals_in, temp, temp_bytes, total;
+  size_t dkeys_in, dkeys_out, dvals_in, dvals_out, starts, tkeys_in, tkeys_out, tvals_in, tvals_tmp, temp, temp_bytes,
+      total;
 };
 
 struct TilesOf {
@@ -706,6 +708,7 @@ static Phase2Layout phase2_layout(int64_t cn, int64_t n_isects) {
   L.tkeys_in = take((size_t)n_isects * 4);
   L.tkeys_out = take((size_t)n_isects * 4);
   L.tvals_in = take((size_t)n_isects * 4);
+  L.tvals_tmp = take((size_t)n_isects * 4);
   size_t t1 = 0, t2 = 0, t3 = 0;
   (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, t1, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                   (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)cn, 0u, 32u);
@@ -718,6 +721,9 @@ static Phase2Layout phase2_layout(int64_t cn, int64_t n_isects) {
   auto it = rocprim::make_transform_iterator((const uint32_t *)nullptr, TilesOf{nullptr});
   (void)rocprim::exclusive_scan(nullptr, t3, it, (uint32_t *)nullptr, 0u, (size_t)cn, rocprim::plus<uint32_t>());
   L.temp_bytes = t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3);
+  // the chained-scan sort's counters: the depth keys' second value buffer (4 * cn bytes) sits in front of them
+  L.temp_bytes = std::max(L.temp_bytes, align256((size_t)cn * 4) + std::max(rs::layout(cn, 4).total,
+                                                                            rs::layout(n_isects, 4).total));
   L.temp = take(L.temp_bytes);
   L.total = off + 256;
   return L;
@@ -733,6 +739,19 @@ __global__ void __launch_bounds__(256) depth_keys_kernel(int64_t total, const fl
   keys[idx] = (!tiles_per_gauss || tiles_per_gauss[idx] > 0) ? (uint32_t)__float_as_int(depths[idx]) : 0xFFFFFFFFu;
   vals[idx] = (uint32_t)idx;
 }
+
+// The same keys as a functor: the chained-scan sort reads them where they are instead of from a key array.
+struct DepthBits {
+  const float *depths;
+  const int32_t *tiles_per_gauss;
+  __device__ __forceinline__ uint32_t operator()(int64_t i) const {
+    return (!tiles_per_gauss || tiles_per_gauss[i] > 0) ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;
+  }
+};
+
+// Which device sort orders the depth keys and the (camera | tile) keys: the chained-scan sort of onesweep.h unless
+// POGS_RAST_DEPTH_SORT=1 asks for rocPRIM's (the cross-check) or the item count exceeds its 30-bit counters.
+static inline bool own_radix_sort(int64_t items) { return tuning().depth_sort != 1 && items <= rs::MAX_ITEMS; }
 
 // Number of valid intersections: the buffers hold `cap`; when the caller sized them before the true count
 // reached the host, the count is read from device memory (and clamped, so an undersized guess stays
@@ -799,26 +818,36 @@ __global__ void __launch_bounds__(256) isect_emit_sorted_kernel(
 }
 
 // Start of every tile's range in the sorted list, from the sorted (camera|tile) keys.
+constexpr int TILE_OFFSETS_ITEMS = 8;   // keys per thread, requested together
 template <class KeyT>
 __global__ void __launch_bounds__(256) tile_offsets_kernel(int64_t cap, const int64_t *__restrict__ n_dev,
                                                            const KeyT *__restrict__ tkeys,
                                                            int n_tiles_total, int tile_bits, int n_tiles,
                                                            int32_t *__restrict__ offsets) {
   const int64_t n_isects = true_count(cap, n_dev);
-  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_isects) return;
   const uint32_t mask = (1u << tile_bits) - 1u;
-  const uint32_t hc = tkeys[k];
-  const int cur = (int)(hc >> tile_bits) * n_tiles + (int)(hc & mask);
-  if (k == 0) {
-    for (int t = 0; t <= cur; ++t) offsets[t] = 0;
-  } else {
-    const uint32_t hp = tkeys[k - 1];
-    const int prev = (int)(hp >> tile_bits) * n_tiles + (int)(hp & mask);
-    for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)k;
+  const int64_t k0 = (int64_t)blockIdx.x * (256 * TILE_OFFSETS_ITEMS) + threadIdx.x;
+  uint32_t hc[TILE_OFFSETS_ITEMS], hp[TILE_OFFSETS_ITEMS];
+#pragma unroll
+  for (int i = 0; i < TILE_OFFSETS_ITEMS; ++i) {
+    const int64_t k = k0 + i * 256;
+    hc[i] = k < n_isects ? (uint32_t)tkeys[k] : 0u;
+    hp[i] = k < n_isects && k > 0 ? (uint32_t)tkeys[k - 1] : 0u;
   }
-  if (k == n_isects - 1)
-    for (int t = cur + 1; t < n_tiles_total; ++t) offsets[t] = (int32_t)n_isects;
+#pragma unroll
+  for (int i = 0; i < TILE_OFFSETS_ITEMS; ++i) {
+    const int64_t k = k0 + i * 256;
+    if (k >= n_isects) break;
+    const int cur = (int)(hc[i] >> tile_bits) * n_tiles + (int)(hc[i] & mask);
+    if (k == 0) {
+      for (int t = 0; t <= cur; ++t) offsets[t] = 0;
+    } else {
+      const int prev = (int)(hp[i] >> tile_bits) * n_tiles + (int)(hp[i] & mask);
+      for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)k;
+    }
+    if (k == n_isects - 1)
+      for (int t = cur + 1; t < n_tiles_total; ++t) offsets[t] = (int32_t)n_isects;
+  }
 }
 
 // Launch order of the compositing kernels: tiles by list length, longest first.  Only the rough order
@@ -836,15 +865,27 @@ __device__ void tile_order_body(int n_tiles_total, const int32_t *__restrict__ o
     const int32_t hi = t + 1 < n_tiles_total ? offsets[t + 1] : (int32_t)n_isects;
     return hi - offsets[t];
   };
+  // every pass over the tiles requests eight lengths per thread before it uses any: a pass costs one memory round
+  // trip per 8192 tiles instead of one per tile and thread
+  auto for_each_tile = [&](auto &&use) {
+    for (int t0 = tid; t0 < n_tiles_total; t0 += 8 * NB) {
+      int len[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) len[i] = t0 + i * NB < n_tiles_total ? length(t0 + i * NB) : 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (t0 + i * NB < n_tiles_total) use(t0 + i * NB, len[i]);
+    }
+  };
   bucket[tid] = 0;
   if (tid == 0) longest = 0;
   __syncthreads();
   int mx = 0;
-  for (int t = tid; t < n_tiles_total; t += NB) mx = max(mx, length(t));
+  for_each_tile([&](int, int len) { mx = max(mx, len); });
   atomicMax(&longest, mx);
   __syncthreads();
   const float scale = longest > 0 ? (float)(NB - 1) / (float)longest : 0.f;
-  for (int t = tid; t < n_tiles_total; t += NB) atomicAdd(&bucket[(int)((float)(longest - length(t)) * scale)], 1);
+  for_each_tile([&](int, int len) { atomicAdd(&bucket[(int)((float)(longest - len) * scale)], 1); });
   __syncthreads();
   // exclusive scan of the 1024 bucket sizes: one value per thread
   const int lane = tid & 63, wave = tid >> 6;
@@ -862,8 +903,7 @@ __device__ void tile_order_body(int n_tiles_total, const int32_t *__restrict__ o
   __syncthreads();
   bucket[tid] = base + incl - mine;  // from here on: the bucket's write cursor
   __syncthreads();
-  for (int t = tid; t < n_tiles_total; t += NB)
-    order[atomicAdd(&bucket[(int)((float)(longest - length(t)) * scale)], 1)] = t;
+  for_each_tile([&](int t, int len) { order[atomicAdd(&bucket[(int)((float)(longest - len) * scale)], 1)] = t; });
 }
 }  // namespace pr
 
@@ -885,6 +925,21 @@ __global__ void __launch_bounds__(256) isect_ids_kernel(int64_t cap, const int64
   isect_ids[k] = ((int64_t)tkeys[k] << 32) | (int64_t)d;
 }
 
+// The intersection count for the host without a copy command: a one-thread kernel stores it into page-locked host
+// memory, then a sequence number next to it; the host polls the sequence word.  A copy plus an event costs two command
+// barriers on the stream (about 10 us of idle GPU each on this hardware); this costs one 2 us launch.
+__global__ void publish_count_kernel(const int64_t *__restrict__ count_dev, int64_t *__restrict__ host_words,
+                                     int64_t sequence) {
+  __hip_atomic_store(host_words, *count_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_words + 1, sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int pr_publish_count(const int64_t *count_dev, int64_t *host_words, int64_t sequence, void *stream) {
+  if (!count_dev || !host_words) return PR_EINVAL;
+  hipLaunchKernelGGL(publish_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, count_dev, host_words, sequence);
+  return check_launch("publish_count_kernel");
+}
+
 extern "C" size_t pr_isect_sort_scratch_bytes(int C, int N, int64_t n_isects, int64_t n_tiles_total) {
   if (n_isects <= 0 || (int64_t)C * N <= 0) return 256;
   (void)n_tiles_total;
@@ -900,7 +955,8 @@ extern "C" size_t pr_depth_order_scratch_bytes(int C, int N) {
   (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, t, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                               (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)cn, 0u, 32u);
   const size_t radix = align256((size_t)cn * 4) * 3 + align256(t) + 256;
-  return std::max(radix, sample_sort_layout(cn).total);
+  const size_t chained = align256((size_t)cn * 4) * 4 + rs::layout(cn, 4).total + 256;
+  return std::max(std::max(radix, chained), sample_sort_layout(cn).total);
 }
 
 static int depth_order_sample_sort(int64_t total, const float *depths, int32_t *depth_order, char *base,
@@ -934,6 +990,12 @@ extern "C" int pr_depth_order(int C, int N, const float *depths, int32_t *depth_
   if (total >= SS_MIN_TOTAL && total <= SS_MAX_TOTAL && tuning().depth_sort == 2)
     return depth_order_sample_sort(total, depths, depth_order, base, (hipStream_t)stream);
   const size_t seg = align256((size_t)total * 4);
+  if (own_radix_sort(total)) {
+    uint32_t *const kbuf[2] = {(uint32_t *)base, (uint32_t *)(base + seg)};
+    uint32_t *const vbuf[2] = {(uint32_t *)(base + 2 * seg), (uint32_t *)(base + 3 * seg)};
+    return rs::sort_pairs<uint32_t>(DepthBits{depths, nullptr}, rs::Iota{}, total, nullptr, 32, kbuf, vbuf,
+                                    (uint32_t *)nullptr, (uint32_t *)depth_order, base + 4 * seg, (hipStream_t)stream);
+  }
   uint32_t *k_in = (uint32_t *)base, *k_out = (uint32_t *)(base + seg), *v_in = (uint32_t *)(base + 2 * seg);
   void *temp = base + 3 * seg;
   size_t tb = scratch_bytes - 3 * seg;
@@ -1010,13 +1072,15 @@ static int emit_and_tile_sort(int C, int N, int64_t total, int64_t n_isects, con
                               int64_t n_tiles_total, int tile_bits, int cam_bits, const uint32_t *dv_out,
                               const uint32_t *starts, const float *means2d, const int32_t *radii, const float *conics,
                               const float *opacities, const int32_t *tiles_per_gauss, const float *depths, int tile_size,
-                              int tile_w, int tile_h, KeyT *tk_in, KeyT *tk_out, uint32_t *tv_in, int32_t *flatten_ids,
+                              int tile_w, int tile_h, KeyT *tk_in, KeyT *tk_out, uint32_t *tv_in, uint32_t *tv_tmp, int32_t *flatten_ids,
                               int32_t *isect_offsets, int32_t *tile_order, int64_t *isect_ids, void *temp,
                               size_t temp_bytes, hipStream_t st) {
   const unsigned grid_n = (unsigned)((total + 255) / 256);
+  const bool own = own_radix_sort(n_isects);
   if (n_isects_dev) {
-    // capacity mode: slots past the true count keep an all-ones key and sort to the end
-    PR_HIP(hipMemsetAsync(tk_in, 0xFF, (size_t)n_isects * sizeof(KeyT), st));
+    // capacity mode: slots past the true count keep an all-ones key and sort to the end (the chained-scan sort reads
+    // the true count itself and never looks at them)
+    if (!own) PR_HIP(hipMemsetAsync(tk_in, 0xFF, (size_t)n_isects * sizeof(KeyT), st));
     if (isect_offsets) PR_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)n_tiles_total * 4, st));
   }
   if (conics)
@@ -1028,13 +1092,25 @@ static int emit_and_tile_sort(int C, int N, int64_t total, int64_t n_isects, con
                        radii, (float)tile_size, tile_w, tile_h, tile_bits, n_isects, n_isects_dev, tk_in, tv_in);
   int rc = check_launch("isect_emit_kernel");
   if (rc) return rc;
-  size_t tb = temp_bytes;
-  PR_HIP(rocprim::radix_sort_pairs<SortConfig>(temp, tb, (const KeyT *)tk_in, tk_out, (const uint32_t *)tv_in,
-                                               (uint32_t *)flatten_ids, (size_t)n_isects, 0u,
-                                               (unsigned)(tile_bits + cam_bits), st));
+  if (own) {
+    const int bits = tile_bits + cam_bits, passes = bits <= 0 ? 1 : (bits + 7) / 8;
+    KeyT *const kbuf[2] = {tk_out, tk_in};
+    uint32_t *const vbuf[2] = {tv_tmp, tv_in};
+    KeyT *sorted = kbuf[(passes - 1) & 1];
+    rc = rs::sort_pairs<KeyT>(rs::FromArray<KeyT>{tk_in}, rs::FromArray<uint32_t>{tv_in}, n_isects, n_isects_dev, bits, kbuf,
+                              vbuf, sorted, (uint32_t *)flatten_ids, (char *)temp, st);
+    if (rc) return rc;
+    tk_out = sorted;
+  } else {
+    size_t tb = temp_bytes;
+    PR_HIP(rocprim::radix_sort_pairs<SortConfig>(temp, tb, (const KeyT *)tk_in, tk_out, (const uint32_t *)tv_in,
+                                                 (uint32_t *)flatten_ids, (size_t)n_isects, 0u,
+                                                 (unsigned)(tile_bits + cam_bits), st));
+  }
   const unsigned grid_i = (unsigned)((n_isects + 255) / 256);
   if (isect_offsets) {
-    hipLaunchKernelGGL(tile_offsets_kernel<KeyT>, dim3(grid_i), dim3(256), 0, st, n_isects, n_isects_dev,
+    const unsigned grid_o = (unsigned)((n_isects + 256 * TILE_OFFSETS_ITEMS - 1) / (256 * TILE_OFFSETS_ITEMS));
+    hipLaunchKernelGGL(tile_offsets_kernel<KeyT>, dim3(grid_o), dim3(256), 0, st, n_isects, n_isects_dev,
                        (const KeyT *)tk_out, (int)n_tiles_total, tile_bits, tile_w * tile_h, isect_offsets);
     rc = check_launch("tile_offsets_kernel");
     if (rc) return rc;
@@ -1087,7 +1163,7 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
   uint32_t *dv_in = (uint32_t *)(base + L.dvals_in), *dv_out = (uint32_t *)(base + L.dvals_out);
   uint32_t *starts = (uint32_t *)(base + L.starts);
   uint32_t *tk_in = (uint32_t *)(base + L.tkeys_in), *tk_out = (uint32_t *)(base + L.tkeys_out);
-  uint32_t *tv_in = (uint32_t *)(base + L.tvals_in);
+  uint32_t *tv_in = (uint32_t *)(base + L.tvals_in), *tv_tmp = (uint32_t *)(base + L.tvals_tmp);
   void *temp = base + L.temp;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid_n = (unsigned)((total + 255) / 256);
@@ -1095,6 +1171,12 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
   size_t tb = L.temp_bytes;
   if (depth_order) {
     dv_out = (uint32_t *)depth_order;  // computed by pr_depth_order
+  } else if (own_radix_sort(total)) {
+    uint32_t *const kbuf[2] = {dk_in, dk_out};
+    uint32_t *const vbuf[2] = {dv_in, (uint32_t *)temp};
+    rc = rs::sort_pairs<uint32_t>(DepthBits{depths, tiles_per_gauss}, rs::Iota{}, total, nullptr, 32, kbuf, vbuf,
+                                  (uint32_t *)nullptr, dv_out, (char *)temp + align256((size_t)total * 4), st);
+    if (rc) return rc;
   } else {
     hipLaunchKernelGGL(depth_keys_kernel, dim3(grid_n), dim3(256), 0, st, total, depths, tiles_per_gauss, dk_in,
                        dv_in);
@@ -1111,11 +1193,11 @@ extern "C" int pr_isect_emit_sort(int C, int N, const float *means2d, const int3
   if (tile_bits + cam_bits <= 16 && n_tiles_total < 65535)
     return emit_and_tile_sort<uint16_t>(C, N, total, n_isects, n_isects_dev, n_tiles_total, tile_bits, cam_bits, dv_out,
                                         starts, means2d, radii, conics, opacities, tiles_per_gauss, depths, tile_size, tile_w,
-                                        tile_h, (uint16_t *)tk_in, (uint16_t *)tk_out, tv_in, flatten_ids, isect_offsets,
+                                        tile_h, (uint16_t *)tk_in, (uint16_t *)tk_out, tv_in, tv_tmp, flatten_ids, isect_offsets,
                                         tile_order, isect_ids, temp, L.temp_bytes, st);
   return emit_and_tile_sort<uint32_t>(C, N, total, n_isects, n_isects_dev, n_tiles_total, tile_bits, cam_bits, dv_out,
                                       starts, means2d, radii, conics, opacities, tiles_per_gauss, depths, tile_size, tile_w,
-                                      tile_h, tk_in, tk_out, tv_in, flatten_ids, isect_offsets, tile_order, isect_ids, temp,
+                                      tile_h, tk_in, tk_out, tv_in, tv_tmp, flatten_ids, isect_offsets, tile_order, isect_ids, temp,
                                       L.temp_bytes, st);
 }
 

@@ -16,6 +16,7 @@ from __future__ import annotations
 import math
 import os
 import threading
+import time
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -125,6 +126,7 @@ class _Projection(torch.autograd.Function):
         ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii)
         ctx.args = (width, height, eps2d)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None instead of freshly filled zero tensors
         return radii, means2d, depths, conics, comps
 
     @staticmethod
@@ -184,6 +186,7 @@ class _ProjectionRigid(torch.autograd.Function):
         ctx.save_for_backward(means, quats, scales, labels, init_p2ws, p_deltas, viewmats, Ks, radii)
         ctx.args = (width, height, eps2d)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
         return radii, means2d, depths, conics, comps, means_world
 
     @staticmethod
@@ -230,11 +233,14 @@ class _SphericalHarmonics(torch.autograd.Function):
                                      int(post), _ptr(colors), 3, _stream())
         ctx.save_for_backward(means, campos, coeffs, radii)
         ctx.args = (degree, int(post))
+        ctx.set_materialize_grads(False)
         return colors
 
     @staticmethod
     def backward(ctx, v_colors):
         lib = _lib.load()
+        if v_colors is None:
+            return None, None, None, None, None, None
         means, campos, coeffs, radii = ctx.saved_tensors
         degree, post = ctx.args
         C, N, K = campos.shape[0], means.shape[0], coeffs.shape[1]
@@ -276,6 +282,10 @@ class _CallState:
         self.pinned: Dict[int, List[Tensor]] = {}
         self.side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
         self.speculate = os.environ.get("POGS_RAST_SPECULATE", "1") != "0"
+        # how a speculating call learns the true count: "publish" = a one-thread kernel stores it into page-locked
+        # memory and the host polls (no copy command, no event on the stream); "event" = copy + event
+        self.readback = os.environ.get("POGS_RAST_COUNT_READBACK", "publish")
+        self.sequence = 0
 
     def guess(self, key) -> Optional[int]:
         """Capacity to size the lists with, or None when the host should wait for the exact count."""
@@ -300,11 +310,17 @@ class _CallState:
             del h[:-self.HISTORY]
 
     def take_pinned(self, dev: torch.device) -> Tensor:
+        """Two page-locked words: [0] the count, [1] the sequence number of the publication that wrote it."""
         with self.lock:
             pool = self.pinned.setdefault(dev.index, [])
             if pool:
                 return pool.pop()
-        return torch.empty(1, dtype=torch.int64, pin_memory=True)
+        return torch.zeros(2, dtype=torch.int64, pin_memory=True)
+
+    def next_sequence(self) -> int:
+        with self.lock:
+            self.sequence += 1
+            return self.sequence
 
     def give_pinned(self, dev: torch.device, t: Tensor) -> None:
         with self.lock:
@@ -351,6 +367,24 @@ def _depth_order_async(depths: Tensor):
     depths.record_stream(side)
     order.record_stream(main)
     return order, done
+
+
+def _await_published(host: Tensor, seq: int, timeout_s: float = 60.0) -> int:
+    """Wait until the kernel of ``pr_publish_count`` has stored sequence number ``seq`` into host[1]; -> host[0]."""
+    words = host.numpy()
+    deadline = None
+    spins = 0
+    while int(words[1]) != seq:
+        spins += 1
+        if spins & 63 == 0:
+            time.sleep(0)                     # let other Python threads run
+            now = time.monotonic()
+            if deadline is None:
+                deadline = now + timeout_s
+            elif now > deadline:
+                raise RuntimeError("pogs_amd: the intersection count never reached the host (sequence %d): %s"
+                                   % (seq, _lib.load().pr_last_hip_error().decode()))
+    return int(words[0])
 
 
 def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int, tile_height: int,
@@ -416,12 +450,18 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
             isect_ids, flatten_ids = emit(n_isects, False)
         else:
             host = _state.take_pinned(dev)
-            host.copy_(cum[-1:], non_blocking=True)
-            done = torch.cuda.Event()
-            done.record()
-            isect_ids, flatten_ids = emit(guess, True)
-            done.synchronize()
-            n_isects = int(host.item())
+            if _state.readback == "publish":
+                seq = _state.next_sequence()
+                _call("pr_publish_count", cum[-1:].data_ptr(), host.data_ptr(), seq, _stream())
+                isect_ids, flatten_ids = emit(guess, True)
+                n_isects = _await_published(host, seq)
+            else:
+                host[:1].copy_(cum[-1:], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+                isect_ids, flatten_ids = emit(guess, True)
+                done.synchronize()
+                n_isects = int(host[0].item())
             _state.give_pinned(dev, host)
             if n_isects > guess:
                 isect_ids, flatten_ids = emit(n_isects, False)
@@ -474,12 +514,12 @@ def _tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, 
             flatten_ids = fill(n_isects)
         else:
             host = _state.take_pinned(dev)
-            host.copy_(total, non_blocking=True)
+            host[:1].copy_(total, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
             flatten_ids = fill(guess)
             done.synchronize()
-            n_isects = int(host.item())
+            n_isects = int(host[0].item())
             _state.give_pinned(dev, host)
             if n_isects > guess:      # the counters were consumed by the undersized fill: count again
                 _call("pr_tile_lists_count", C, N, _ptr(means2d), _ptr(radii), _ptr(conics), _ptr(opacities),
@@ -600,6 +640,30 @@ def _segments(parts, C, N):
     return tensors, items
 
 
+_EARLY_FILL_MIN_BYTES = 32 << 20
+
+
+def _grad_targets(parts, want, geom, C, N, dev):
+    """Zero-filled accumulation targets of the backward compositor: the packed geometry gradients [C*N,8] and the
+    narrow colour parts (rgb, depth) share one allocation and one fill; wide parts (features) get their own.
+    -> (v_geom or None, [gradient buffer or None per part])."""
+    pooled = [w and p.shape[-1] <= 4 for w, p in zip(want, parts)]
+    n_pool = (C * N * 8 if geom else 0) + sum((p.numel() + 7) // 8 * 8 for p, k in zip(parts, pooled) if k)
+    pool = torch.zeros(n_pool, dtype=torch.float32, device=dev) if n_pool else None
+    at = C * N * 8 if geom else 0
+    v_geom = pool[:at].view(C * N, 8) if geom else None
+    v_parts = []
+    for p, w, k in zip(parts, want, pooled):
+        if not w:
+            v_parts.append(None)
+        elif k:
+            v_parts.append(pool[at:at + p.numel()].view(p.shape))
+            at += (p.numel() + 7) // 8 * 8
+        else:
+            v_parts.append(torch.zeros_like(p))
+    return v_geom, v_parts
+
+
 class _Rasterize(torch.autograd.Function):
     """Tile compositing; stands in for gsplat ``rasterize_to_pixels``.  The composited channels are the
     concatenation of up to three tensors (``part0 | part1 | part2``, each [C,N,w] or -- shared by all cameras --
@@ -635,6 +699,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.args = (width, height, tile_size, absgrad, ed_channel, items,
                     [i for i, p in enumerate((part0, part1, part2)) if p is not None])
         ctx.means2d_obj = means2d  # the object callers hold in meta["means2d"]; receives .absgrad
+        ctx.set_materialize_grads(False)
         return render_colors, render_alphas
 
     @staticmethod
@@ -653,23 +718,24 @@ class _Rasterize(torch.autograd.Function):
             v_render_alphas = torch.zeros(C, height, width, 1, dtype=torch.float32, device=dev)
         v_render_colors, v_render_alphas = v_render_colors.contiguous(), v_render_alphas.contiguous()
         geom = ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[5]
-        # the accumulation targets start at zero: the packed geometry gradients and the narrow colour parts (rgb, depth)
-        # share one allocation and one fill; wide parts (features) get their own
         want = [bool(ctx.needs_input_grad[2 + slot]) for slot in slots]
-        pooled = [w and p.shape[-1] <= 4 for w, p in zip(want, parts)]
-        n_pool = (C * N * 8 if geom else 0) + sum((p.numel() + 7) // 8 * 8 for p, k in zip(parts, pooled) if k)
-        pool = torch.zeros(n_pool, dtype=torch.float32, device=dev) if n_pool else None
-        at = C * N * 8 if geom else 0
-        v_geom = pool[:at].view(C * N, 8) if geom else None
-        v_parts = []
-        for p, w, k in zip(parts, want, pooled):
-            if not w:
-                v_parts.append(None)
-            elif k:
-                v_parts.append(pool[at:at + p.numel()].view(p.shape))
-                at += (p.numel() + 7) // 8 * 8
-            else:
-                v_parts.append(torch.zeros_like(p))
+        # The kernel accumulates into zero-filled buffers.  For a large model filling them is 20-40 us of pure memory
+        # traffic in front of the backward kernel.  The host usually reaches this point while the GPU is still in the
+        # forward compositor (bound by vector instructions): issued on the second stream the fills run under it.
+        n_bytes = 4 * ((C * N * 8 if geom else 0) + sum(p.numel() for p, w in zip(parts, want) if w))
+        if n_bytes >= _EARLY_FILL_MIN_BYTES:
+            main = torch.cuda.current_stream(dev)
+            side = _state.side_stream(dev, main)
+            with torch.cuda.stream(side):
+                v_geom, v_parts = _grad_targets(parts, want, geom, C, N, dev)
+                filled = torch.cuda.Event()
+                filled.record(side)
+            main.wait_event(filled)
+            for t in [v_geom] + v_parts:
+                if t is not None:
+                    t.record_stream(main)
+        else:
+            v_geom, v_parts = _grad_targets(parts, want, geom, C, N, dev)
         if geom or any(v is not None for v in v_parts):
             single = len(parts) == 1 and not items[0][3]
             keep_c, segs = (None, None) if single else _lib.segment_array(items)

@@ -1,7 +1,8 @@
 """pr_depth_order: the order of the C*N Gaussians by (depth bits, flat index) -- what a stable sort of the depth bits
-gives, and what gsplat's 64-bit (tile | depth) sort resolves ties with.  Default: radix sort.  POGS_RAST_DEPTH_SORT=2
-selects a sample sort between 32 K and 1.25 M Gaussians (splitters from 8192 samples, one LDS sort per bucket); both
-against torch's stable sort, on distributions chosen to unbalance the buckets."""
+gives, and what gsplat's 64-bit (tile | depth) sort resolves ties with.  Default: the library's own chained-scan radix
+sort; POGS_RAST_DEPTH_SORT=1 selects rocPRIM's radix sort, =2 a sample sort between 32 K and 1.25 M Gaussians
+(splitters from 8192 samples, one LDS sort per bucket); all three against torch's stable sort, on distributions chosen
+to unbalance buckets and digits."""
 import ctypes
 
 import pytest
@@ -31,19 +32,22 @@ def _cases(n, gen):
     yield "exponential", torch.empty(n).exponential_(1.0, generator=gen) + 0.01
     d = torch.rand(n, generator=gen) * 40 + 0.05
     d[torch.rand(n, generator=gen) < 0.5] = 0.0            # culled entries are zeros
-    d[n // 3:n // 3 + 5000] = d[7]                         # a run of ties
+    d[n // 3:n // 3 + 5000] = d[min(7, n - 1)]             # a run of ties
     yield "half culled with ties", d
     yield "few distinct values", torch.randint(0, 5, (n,), generator=gen).float() + 1.0
     yield "sorted descending", torch.arange(n, 0, -1).float()
 
 
-@pytest.mark.parametrize("which", ["radix", "sample"])
+_SORTS = {"chained": None, "rocprim": "1", "sample": "2"}
+
+
+@pytest.mark.parametrize("which", list(_SORTS))
 @pytest.mark.parametrize("n", [32_767, 32_768, 100_003, 1_000_000, 1_250_000, 1_250_001])
 def test_depth_order_matches_a_stable_sort(gpu, n, which, tuning):
     from pogs_amd import _lib
 
     lib = _lib.load()
-    tuning(POGS_RAST_DEPTH_SORT="2" if which == "sample" else None)
+    tuning(POGS_RAST_DEPTH_SORT=_SORTS[which])
     gen = torch.Generator().manual_seed(n)
     for name, d in _cases(n, gen):
         d = d.to(gpu).view(1, n)
@@ -55,6 +59,19 @@ def test_depth_order_matches_a_stable_sort(gpu, n, which, tuning):
     assert torch.equal(_order(lib, d).long(), torch.sort(d.flatten().view(torch.int32), stable=True).indices)
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 4095, 4096, 4097, 8192, 12_289])
+def test_chained_sort_around_its_tile_size(gpu, n):
+    """One tile of the chained-scan sort holds 4096 pairs: sizes around one and two tiles, and tiny ones."""
+    from pogs_amd import _lib
+
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(n)
+    for name, d in _cases(n, gen):
+        d = d.to(gpu).view(1, n)
+        want = torch.sort(d.flatten().view(torch.int32), stable=True).indices
+        assert torch.equal(_order(lib, d).long(), want), (name, n)
+
+
 def test_both_sorts_agree(gpu, tuning):
     from pogs_amd import _lib
 
@@ -64,3 +81,5 @@ def test_both_sorts_agree(gpu, tuning):
     tuning(POGS_RAST_DEPTH_SORT="2")       # sample sort
     b = _order(lib, d)
     assert torch.equal(a, b)
+    tuning(POGS_RAST_DEPTH_SORT="1")       # rocPRIM
+    assert torch.equal(a, _order(lib, d))
