@@ -460,6 +460,13 @@ def main():
             _lib.set_tuning(POGS_RAST_FWD_MFMA=cur if cur else None)
             variant("two_call", "unmodified-POGS call pattern: RGB+ED and the features as two rasterization() calls "
                                 "(pogs/pogs.py:352,493)", two_call=not args.two_call)
+            _lib.set_tuning(POGS_RAST_BWD_MFMA=3)
+            variant("bwd_deferred_split_bf16", "backward: colour-gradient contraction of the first 32 channels deferred to "
+                    "three bf16 matrix products per 16 contributing Gaussians (raster_bwd_cmfma_kernel), opt-in")
+            _lib.set_tuning(POGS_RAST_BWD_MFMA=4, POGS_RAST_BWD_SPLIT=1)
+            variant("bwd_split_two_streams", "backward: geometry-only kernel and matrix-core colour-gradient kernel "
+                    "(raster_bwd_colour_mfma_kernel) side by side on two streams, opt-in")
+            _lib.set_tuning(POGS_RAST_BWD_MFMA=None, POGS_RAST_BWD_SPLIT=None)
             rendering.set_count_speculation(False)
             variant("no_count_speculation", "every call waits on the host for its intersection count, as gsplat does")
             rendering.set_count_speculation(True)

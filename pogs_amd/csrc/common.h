@@ -41,7 +41,10 @@ struct Tuning {
   int fwd_chunk;    // POGS_RAST_FWD_CHUNK: widest forward channel pass (0 = planner)
   int fwd_mfma;     // POGS_RAST_FWD_MFMA: 1 = split-bf16 matrix-core colour accumulation for 32..72-channel passes
   int bwd_ppl;      // POGS_RAST_BWD_PPL: as fwd_ppl for the backward compositor
-  int bwd_mfma;     // POGS_RAST_BWD_MFMA: 0 = vector kernels only for the geometry-only backward
+  int bwd_mfma;     // POGS_RAST_BWD_MFMA: 0 = vector kernels only; 1 (default) = matrix-core dot products in the geometry-only
+                    // backward at 1 pixel per lane; 2 = both contractions on the matrix cores at 1 pixel per lane;
+                    // 3 = deferred matrix-core colour gradient at 2 pixels per lane (32/36-channel passes);
+                    // 4 = colour gradients in a kernel of their own on the matrix cores (up to 48 channels)
   int mlp_variant;  // POGS_MLP_VARIANT: -1 = default
   int depth_sort;   // POGS_RAST_DEPTH_SORT: 0 = chained-scan radix sort (onesweep.h), 1 = rocPRIM's radix sort for both binning
                     // sorts, 2 = sample sort of the depth keys between 32 K and 1.25 M Gaussians

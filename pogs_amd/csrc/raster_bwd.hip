@@ -1044,6 +1044,30 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
   if (ed_channel >= D || (ed_channel >= 0 && !render_colors)) return PR_EINVAL;
   if (!geom_grad && !any_color_grad) return PR_OK;
   if ((int64_t)C * tile_w * tile_h * 4 > 2147483647ll) return PR_EUNSUPPORTED;
+  // Colour gradients alone, up to 48 channels: the forward walk replayed on the records, contraction on the matrix cores
+  if (!geom_grad && any_color_grad && tile_size == 16 && tuning().bwd_mfma == 4 && D <= 48)
+    return launch_bwd_colour_mfma(C, N, D, means2d, conics, opacities, width, height, tile_w, tile_h, isect_offsets,
+                                  tile_order, flatten_ids, render_alphas, last_ids, ed_channel, v_render_colors, gs,
+                                  (hipStream_t)stream);
+  // Both kinds of gradients, up to 48 channels: the geometry-only kernel, then the colour gradients by themselves with
+  // their contraction on the matrix cores (raster_bwd_cmfma.hip)
+  if (geom_grad && any_color_grad && tile_size == 16 && tuning().bwd_mfma == 4 && D <= 48) {
+    pr_grad_segment none[3];
+    for (int i = 0; i < 3; ++i) {
+      none[i].ptr = nullptr;
+      none[i].width = i < n_segments ? v_segments[i].width : 0;
+      none[i].ld = i < n_segments ? v_segments[i].ld : 0;
+      none[i].shared = i < n_segments ? v_segments[i].shared : 0;
+    }
+    const int rc = pr_raster_bwd(C, N, D, means2d, conics, colors, opacities, backgrounds, width, height, tile_size,
+                                 tile_w, tile_h, isect_offsets, tile_order, flatten_ids, n_isects, render_alphas,
+                                 last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas, absgrad, 1, v_geom,
+                                 nullptr, segments, none, n_segments, stream);
+    if (rc) return rc;
+    return launch_bwd_colour_mfma(C, N, D, means2d, conics, opacities, width, height, tile_w, tile_h, isect_offsets,
+                                  tile_order, flatten_ids, render_alphas, last_ids, ed_channel, v_render_colors, gs,
+                                  (hipStream_t)stream);
+  }
   const BwdPlan plan = plan_bwd(D, geom_grad, any_color_grad, tile_size, (int64_t)C * tile_w * tile_h);
   // geometry gradients only, 16x16 tiles at 1 pixel per lane: the dot products go to the matrix cores
   if (geom_grad && !any_color_grad && tile_size == 16 && plan.ppl == 1 && tuning().bwd_mfma != 0) {
@@ -1079,6 +1103,15 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
       default: break;
     }
 #undef FULL_MFMA_ARGS
+  }
+  // geometry + colour gradients at 2 pixels per lane with the colour-gradient contraction on the matrix cores
+  if (geom_grad && any_color_grad && tile_size == 16 && tuning().bwd_mfma == 3 && plan.per == D && plan.ppl == 2) {
+    const int cd = pick_chunk(D);
+    if (cd == 32 || cd == 36)
+      return launch_bwd_cmfma(cd, C, N, D, means2d, conics, cs, opacities, backgrounds, width, height, tile_w,
+                              tile_h, isect_offsets, tile_order, flatten_ids, n_isects, render_alphas, last_ids,
+                              render_colors, ed_channel, v_render_colors, v_render_alphas, absgrad, v_geom, gs,
+                              (hipStream_t)stream);
   }
   for (int off = 0; off < D; off += plan.per) {
     const int cd = pick_chunk(min(plan.per, D - off));

@@ -178,6 +178,23 @@ inline int make_grad_segs(float *v_colors, int D, const pr_grad_segment *segment
   return make_segs(v_colors, D, segments, n_segments, true, true, out);
 }
 
+// raster_bwd_cmfma.hip: backward at 2 pixels per lane with the colour-gradient contraction on the matrix cores
+// (passes of 32 or 36 channels, geometry and colour gradients both wanted)
+int launch_bwd_cmfma(int cd, int C, int N, int D, const float *means2d, const float *conics, const ColorSegs &cs,
+                     const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
+                     const int32_t *isect_offsets, const int32_t *tile_order, const int32_t *flatten_ids,
+                     int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
+                     const float *render_colors, int ed_channel, const float *v_render_colors,
+                     const float *v_render_alphas, int absgrad, float *v_geom, const GradSegs &gs,
+                     hipStream_t stream);
+
+// colour gradients alone (any pass of up to 48 channels), contraction on the matrix cores
+int launch_bwd_colour_mfma(int C, int N, int D, const float *means2d, const float *conics, const float *opacities,
+                           int width, int height, int tile_w, int tile_h, const int32_t *isect_offsets,
+                           const int32_t *tile_order, const int32_t *flatten_ids, const float *render_alphas,
+                           const int32_t *last_ids, int ed_channel, const float *v_render_colors, const GradSegs &gs,
+                           hipStream_t stream);
+
 // The geometry of one batch of up to 64 intersections, one per lane, loaded ahead of time: the ids and the
 // records they point to are two dependent global round trips, which the caller issues a whole batch early
 // (right after staging the previous one) so that only the colour rows remain to be fetched at staging time.

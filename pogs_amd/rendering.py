@@ -643,6 +643,13 @@ def _segments(parts, C, N):
 _EARLY_FILL_MIN_BYTES = 32 << 20
 
 
+def _split_backward(D: int, tile_size: int) -> bool:
+    """Run the backward compositor as two concurrent kernels (geometry | colour gradients)?  Opt-in through
+    POGS_RAST_BWD_SPLIT=1; the colour half runs on the matrix cores when POGS_RAST_BWD_MFMA=4 (16x16 tiles, up to
+    48 channels)."""
+    return tile_size == 16 and D <= 48 and os.environ.get("POGS_RAST_BWD_SPLIT", "0") == "1"
+
+
 def _grad_targets(parts, want, geom, C, N, dev):
     """Zero-filled accumulation targets of the backward compositor: the packed geometry gradients [C*N,8] and the
     narrow colour parts (rgb, depth) share one allocation and one fill; wide parts (features) get their own.
@@ -739,16 +746,36 @@ class _Rasterize(torch.autograd.Function):
         if geom or any(v is not None for v in v_parts):
             single = len(parts) == 1 and not items[0][3]
             keep_c, segs = (None, None) if single else _lib.segment_array(items)
-            keep_g, vsegs = (None, None) if single else _lib.segment_array(
-                [(None if v is None else v.data_ptr(), w, ld, sh) for v, (_, w, ld, sh) in zip(v_parts, items)])
-            with torch.cuda.device(dev):
-                _call("pr_raster_bwd", C, N, D, _ptr(means2d), _ptr(conics), _ptr(parts[0]) if single else None,
-                      _ptr(opacities), _ptr(backgrounds), width, height, tile_size, tw, th, _ptr(isect_offsets),
-                      _ptr(tile_order), _ptr(flatten_ids), flatten_ids.numel(), _ptr(render_alphas), _ptr(last_ids),
-                      _ptr(render_colors), ed_channel, _ptr(v_render_colors), _ptr(v_render_alphas), int(absgrad),
-                      int(geom), _ptr(v_geom), _ptr(v_parts[0]) if single else None, segs, vsegs,
-                      0 if single else len(items), _stream())
-            del keep_c, keep_g
+
+            def launch(geom_flag, vg, vps):
+                keep_g, vsegs = (None, None) if single else _lib.segment_array(
+                    [(None if v is None else v.data_ptr(), w, ld, sh) for v, (_, w, ld, sh) in zip(vps, items)])
+                with torch.cuda.device(dev):
+                    _call("pr_raster_bwd", C, N, D, _ptr(means2d), _ptr(conics), _ptr(parts[0]) if single else None,
+                          _ptr(opacities), _ptr(backgrounds), width, height, tile_size, tw, th, _ptr(isect_offsets),
+                          _ptr(tile_order), _ptr(flatten_ids), flatten_ids.numel(), _ptr(render_alphas),
+                          _ptr(last_ids), _ptr(render_colors), ed_channel, _ptr(v_render_colors),
+                          _ptr(v_render_alphas), int(absgrad), int(geom_flag), _ptr(vg),
+                          _ptr(vps[0]) if single else None, segs, vsegs, 0 if single else len(items), _stream())
+                del keep_g
+
+            if geom and any(v is not None for v in v_parts) and _split_backward(D, tile_size):
+                # The geometry gradients (bound by vector instructions) and the colour gradients (deferred matrix
+                # product, bound by the float atomics that deliver it) as two kernels that run side by side.
+                main = torch.cuda.current_stream(dev)
+                side = _state.side_stream(dev, main)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    launch(False, None, v_parts)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                launch(True, v_geom, [None] * len(v_parts))
+                main.wait_event(done)
+            else:
+                launch(geom, v_geom, v_parts)
+            del keep_c
         v_means2d = v_conics = v_opacities = None
         if geom:
             g = v_geom.view(C, N, 8)

@@ -707,6 +707,115 @@ def test_rasterization_end_to_end_with_matrix_core_backward(gpu, tuning):
     assert_grad_close(a["viewmats"].grad[:, :3, :], b["viewmats"].grad[:, :3, :], "viewmats")
 
 
+@pytest.mark.parametrize("D", [32, 36, 33])
+@pytest.mark.parametrize("with_bg", [False, True])
+def test_raster_backward_deferred_colour_gradient_on_matrix_cores(gpu, tuning, D, with_bg):
+    """raster_bwd_cmfma_kernel (POGS_RAST_BWD_MFMA=3, 2 pixels per lane): the colour-gradient contraction sum_p fac * v
+    of the first 32 channels as a deferred split-bf16 matrix product over 16 contributing Gaussians at a time, the dot
+    product S, the geometry and the channels past 32 on the vector ALU; against the float64 oracle, |v_xy| against the
+    float32 C restatement.  Tile lists here run from a handful of entries (a last, partly filled block of rows only)
+    to several full blocks."""
+    rd = _rendering()
+    from oracle import raster_c as RC
+    from pogs_amd import _lib
+
+    tuning(POGS_RAST_BWD_MFMA=3, POGS_RAST_BWD_PPL=2)
+    got_ppl, per, _ = _lib.raster_plan(D, 16, 2 * 5 * 3, backward=True, geom_grad=True, color_grad=True)
+    assert got_ppl == 2 and per == D
+    sc = small_scene(n=600, w=70, h=45, views=2, seed=4, lo=0.02, hi=0.3)
+    dev, offs, flat = _staged(gpu, sc, D, 16)
+    bg = torch.rand(2, D, generator=torch.Generator().manual_seed(9)).to(gpu) if with_bg else None
+    cpu, out_r, alpha_r, amb = _oracle_raster(dev, offs, flat, sc, 16, bg, True)
+    g = torch.Generator().manual_seed(13)
+    keep = (~amb)[..., None].float()
+    vc, va = torch.randn(out_r.shape, generator=g) * keep, torch.randn(alpha_r.shape, generator=g) * keep
+    (out_r * vc.double()).sum().add((alpha_r * va.double()).sum()).backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in dev.items()}
+    out, alpha = rd.rasterize_to_pixels(leaves["means2d"], leaves["conics"], leaves["colors"], leaves["opacities"],
+                                        sc.width, sc.height, 16, offs, flat, backgrounds=bg, absgrad=True)
+    ((out * vc.to(gpu)).sum() + (alpha * va.to(gpu)).sum()).backward()
+    for k in ("colors", "opacities", "conics", "means2d"):
+        assert_grad_close(leaves[k].grad, cpu[k].grad, f"{k} D={D} deferred matrix-core colour gradient")
+    o32, a32, last = RC.raster_fwd(dev["means2d"].cpu(), dev["conics"].cpu(), dev["colors"].cpu(),
+                                   dev["opacities"].cpu(), sc.width, sc.height, 16, offs.cpu(), flat.cpu(),
+                                   backgrounds=None if bg is None else bg.cpu())
+    _, v_abs, _, _, _ = RC.raster_bwd(dev["means2d"].cpu(), dev["conics"].cpu(), dev["colors"].cpu(),
+                                      dev["opacities"].cpu(), sc.width, sc.height, 16, offs.cpu(), flat.cpu(), a32,
+                                      last, vc, va, backgrounds=None if bg is None else bg.cpu())
+    assert_grad_close(leaves["means2d"].absgrad, v_abs, f"absgrad D={D}", rtol=2e-3, atol_frac=2e-4)
+
+
+def test_rasterization_end_to_end_with_deferred_colour_gradient(gpu, tuning):
+    """The whole call at the training step's channel layout ([rgb from SH | 32 features | expected depth], gathered
+    from three tensors, gradients scattered into three: the matrix-core columns straddle two of them) with the
+    deferred matrix-core colour gradient."""
+    rd = _rendering()
+    tuning(POGS_RAST_BWD_MFMA=3, POGS_RAST_BWD_PPL=2)
+    sc = small_scene(n=500, w=70, h=45, views=2, seed=8, lo=0.02, hi=0.3, f=32)
+    kw = dict(sh_degree=3, render_mode="RGB+ED", tile_size=16, packed=False, absgrad=True)
+    a = scene_args(sc, device=gpu, requires_grad=True)
+    out, alpha, meta = rd.rasterization(**a, **kw)
+    b = scene_args(sc, dtype=torch.float64, requires_grad=True)
+    out_r, alpha_r, meta_r = R.rasterization(**b, **kw, radii_override=meta["radii"].cpu())
+    amb = meta_r["ambiguous"]
+    g = torch.Generator().manual_seed(21)
+    keep = (~amb)[..., None].float()
+    vc, va = torch.randn(out_r.shape, generator=g) * keep, torch.randn(alpha_r.shape, generator=g) * keep
+    ((out * vc.to(gpu)).sum() + (alpha * va.to(gpu)).sum()).backward()
+    (out_r * vc.double()).sum().add((alpha_r * va.double()).sum()).backward()
+    for k in ("means", "quats", "scales", "opacities", "colors", "features"):
+        assert_grad_close(a[k].grad, b[k].grad, k)
+    assert_grad_close(a["viewmats"].grad[:, :3, :], b["viewmats"].grad[:, :3, :], "viewmats")
+
+
+@pytest.mark.parametrize("D", [4, 19, 32, 36, 33, 48])
+@pytest.mark.parametrize("with_bg", [False, True])
+def test_raster_backward_split_into_geometry_and_matrix_core_colour_kernels(gpu, tuning, D, with_bg):
+    """POGS_RAST_BWD_MFMA=4: the geometry-only backward kernel followed by raster_bwd_colour_mfma_kernel, which
+    replays the forward walk on the records alone and contracts weight x cotangent for every channel on the matrix
+    cores; against the float64 oracle.  D = 36 with the depth channel last is the training step's layout."""
+    rd = _rendering()
+    tuning(POGS_RAST_BWD_MFMA=4)
+    sc = small_scene(n=600, w=70, h=45, views=2, seed=4, lo=0.02, hi=0.3)
+    dev, offs, flat = _staged(gpu, sc, D, 16)
+    bg = torch.rand(2, D, generator=torch.Generator().manual_seed(9)).to(gpu) if with_bg else None
+    cpu, out_r, alpha_r, amb = _oracle_raster(dev, offs, flat, sc, 16, bg, True)
+    g = torch.Generator().manual_seed(13)
+    keep = (~amb)[..., None].float()
+    vc, va = torch.randn(out_r.shape, generator=g) * keep, torch.randn(alpha_r.shape, generator=g) * keep
+    (out_r * vc.double()).sum().add((alpha_r * va.double()).sum()).backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in dev.items()}
+    out, alpha = rd.rasterize_to_pixels(leaves["means2d"], leaves["conics"], leaves["colors"], leaves["opacities"],
+                                        sc.width, sc.height, 16, offs, flat, backgrounds=bg, absgrad=True)
+    ((out * vc.to(gpu)).sum() + (alpha * va.to(gpu)).sum()).backward()
+    for k in ("colors", "opacities", "conics", "means2d"):
+        assert_grad_close(leaves[k].grad, cpu[k].grad, f"{k} D={D} split backward")
+
+
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_rasterization_end_to_end_with_split_backward(gpu, tuning, two_streams):
+    """The whole call at the training step's channel layout ([rgb from SH | 32 features | expected depth], three
+    tensors in, three gradient tensors out, the depth channel's cotangent scaled by 1/alpha) with the split backward:
+    both kernels behind one library call, or (POGS_RAST_BWD_SPLIT=1) as two library calls on two streams."""
+    rd = _rendering()
+    tuning(POGS_RAST_BWD_MFMA=4, POGS_RAST_BWD_SPLIT=1 if two_streams else None)
+    sc = small_scene(n=500, w=70, h=45, views=2, seed=8, lo=0.02, hi=0.3, f=32)
+    kw = dict(sh_degree=3, render_mode="RGB+ED", tile_size=16, packed=False, absgrad=True)
+    a = scene_args(sc, device=gpu, requires_grad=True)
+    out, alpha, meta = rd.rasterization(**a, **kw)
+    b = scene_args(sc, dtype=torch.float64, requires_grad=True)
+    out_r, alpha_r, meta_r = R.rasterization(**b, **kw, radii_override=meta["radii"].cpu())
+    amb = meta_r["ambiguous"]
+    g = torch.Generator().manual_seed(21)
+    keep = (~amb)[..., None].float()
+    vc, va = torch.randn(out_r.shape, generator=g) * keep, torch.randn(alpha_r.shape, generator=g) * keep
+    ((out * vc.to(gpu)).sum() + (alpha * va.to(gpu)).sum()).backward()
+    (out_r * vc.double()).sum().add((alpha_r * va.double()).sum()).backward()
+    for k in ("means", "quats", "scales", "opacities", "colors", "features"):
+        assert_grad_close(a[k].grad, b[k].grad, k)
+    assert_grad_close(a["viewmats"].grad[:, :3, :], b["viewmats"].grad[:, :3, :], "viewmats")
+
+
 @pytest.mark.parametrize("features,expect", [(32, (2, 2)), (0, (2, 2))])
 def test_planner_selected_large_image_kernels(gpu, tuning, features, expect):
     """No tuning variable involved: at 1024x768 (3072 tiles) the planner itself picks the kernels of a full-size
