@@ -17,6 +17,8 @@
 namespace pr {
 namespace rs {
 
+// 16 pairs per thread: measured against 12 and 8 (more workgroups per CU, more tiles in the chain) at 6.4 M tile keys
+// and 1 M depth keys: 0.272 / 0.284 / 0.303 ms for the tile sort's entry point, 0.115 / 0.125 / 0.132 for the depth order
 constexpr int THREADS = 256, WAVES = THREADS / WAVE, BINS = 256, ITEMS = 16, TILE = THREADS * ITEMS;
 constexpr int MAX_PASSES = 4, MAX_HIST_BLOCKS = 256, MAX_GROUPS = 4;   // MAX_HIST_BLOCKS / ROWS_PER_GROUP
 constexpr int64_t HIST_CHUNK = TILE;   // keys a histogram workgroup requests together

@@ -127,6 +127,6 @@ def run_cases(cases, seed, dev, large=False, only=-1, log=print, oracle_chunk=32
                 continue
             raise FuzzFailure(f"{desc}\n    {str(e)[:300]}") from e
         ok += 1
-        if case % 10 == 9 and cases > 200:
+        if (case % 10 == 9 and cases > 200) or (large and case % 5 == 4):
             log(f"{case + 1} cases ok, {time.time() - t0:.0f} s")
     return {"ok": ok, "near": near, "ties": ties, "seconds": time.time() - t0}
