@@ -792,13 +792,14 @@ def test_raster_backward_split_into_geometry_and_matrix_core_colour_kernels(gpu,
         assert_grad_close(leaves[k].grad, cpu[k].grad, f"{k} D={D} split backward")
 
 
-@pytest.mark.parametrize("two_streams", [False, True])
-def test_rasterization_end_to_end_with_split_backward(gpu, tuning, two_streams):
+@pytest.mark.parametrize("two_streams,colour_kernel", [(False, 4), (True, 4), (True, None)])
+def test_rasterization_end_to_end_with_split_backward(gpu, tuning, two_streams, colour_kernel):
     """The whole call at the training step's channel layout ([rgb from SH | 32 features | expected depth], three
     tensors in, three gradient tensors out, the depth channel's cotangent scaled by 1/alpha) with the split backward:
-    both kernels behind one library call, or (POGS_RAST_BWD_SPLIT=1) as two library calls on two streams."""
+    both kernels behind one library call, or (POGS_RAST_BWD_SPLIT=1) as two library calls on two streams -- there also
+    with the library's default colour-only kernel (vector unit) as the second call."""
     rd = _rendering()
-    tuning(POGS_RAST_BWD_MFMA=4, POGS_RAST_BWD_SPLIT=1 if two_streams else None)
+    tuning(POGS_RAST_BWD_MFMA=colour_kernel, POGS_RAST_BWD_SPLIT=1 if two_streams else None)
     sc = small_scene(n=500, w=70, h=45, views=2, seed=8, lo=0.02, hi=0.3, f=32)
     kw = dict(sh_degree=3, render_mode="RGB+ED", tile_size=16, packed=False, absgrad=True)
     a = scene_args(sc, device=gpu, requires_grad=True)
