@@ -996,8 +996,11 @@ extern "C" int pr_raster_bwd_plan(int D, int tile_size, int64_t n_tiles_total, i
   if (channels_per_pass) *channels_per_pass = plan.per;
   if (matrix_cores) {
     const int cd = pick_chunk(D);
-    *matrix_cores = geom_grad && !color_grad && tile_size == 16 && plan.ppl == 1 && tuning().bwd_mfma != 0 &&
-                    cd >= 16 && cd <= 72;
+    const int mode = tuning().bwd_mfma;
+    *matrix_cores = (geom_grad && !color_grad && tile_size == 16 && plan.ppl == 1 && mode != 0 && cd >= 16 && cd <= 72) ||
+                    (geom_grad && color_grad && tile_size == 16 && mode == 2 && plan.per == D && (cd == 32 || cd == 36 || cd == 64 || cd == 72)) ||
+                    (geom_grad && color_grad && tile_size == 16 && mode == 3 && plan.per == D && plan.ppl == 2 && (cd == 32 || cd == 36)) ||
+                    (color_grad && tile_size == 16 && mode == 4 && D <= 48);
   }
   return PR_OK;
 }

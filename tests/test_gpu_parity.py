@@ -720,8 +720,8 @@ def test_raster_backward_deferred_colour_gradient_on_matrix_cores(gpu, tuning, D
     from pogs_amd import _lib
 
     tuning(POGS_RAST_BWD_MFMA=3, POGS_RAST_BWD_PPL=2)
-    got_ppl, per, _ = _lib.raster_plan(D, 16, 2 * 5 * 3, backward=True, geom_grad=True, color_grad=True)
-    assert got_ppl == 2 and per == D
+    got_ppl, per, on_matrix = _lib.raster_plan(D, 16, 2 * 5 * 3, backward=True, geom_grad=True, color_grad=True)
+    assert got_ppl == 2 and per == D and on_matrix
     sc = small_scene(n=600, w=70, h=45, views=2, seed=4, lo=0.02, hi=0.3)
     dev, offs, flat = _staged(gpu, sc, D, 16)
     bg = torch.rand(2, D, generator=torch.Generator().manual_seed(9)).to(gpu) if with_bg else None
