@@ -817,6 +817,53 @@ def test_rasterization_end_to_end_with_split_backward(gpu, tuning, two_streams, 
     assert_grad_close(a["viewmats"].grad[:, :3, :], b["viewmats"].grad[:, :3, :], "viewmats")
 
 
+def test_backward_variants_agree_on_long_tile_lists(gpu, tuning):
+    """200 k Gaussians at 1024x768 (3072 tiles: the planner itself picks 2 pixels per lane; tile lists of several hundred
+    entries, i.e. many 16-row products and staging batches per wavefront, tiles visited in the heaviest-first order):
+    the deferred matrix-core colour gradient, the split backward and the split backward on two streams against the
+    vector kernel, which the float64 oracle checks at the sizes it can reach.  Every gradient of the call is compared."""
+    rd = _rendering()
+    from pogs_amd import _lib
+    from pogs_amd.scenes import make_scene
+
+    W, H, F = 1024, 768, 32
+    sc = make_scene(200_000, W, H, n_features=F, seed=2)
+    p = {k: v.to(gpu).requires_grad_(True) for k, v in dict(means=sc.means, quats=sc.quats, ls=sc.log_scales,
+                                                             ol=sc.opacity_logits, sh=sc.sh, f=sc.features).items()}
+    vm, K = sc.viewmats.to(gpu), sc.Ks.to(gpu)
+    g = torch.Generator().manual_seed(3)
+    vc, va = torch.randn(1, H, W, F + 4, generator=g).to(gpu), torch.randn(1, H, W, 1, generator=g).to(gpu)
+
+    def grads(**env):
+        tuning(**env)
+        assert _lib.raster_plan(F + 4, 16, 64 * 48, backward=True)[:2] == (2, F + 4)
+        for t in p.values():
+            t.grad = None
+        r, a, meta = rd.rasterization(p["means"], p["quats"], p["ls"].exp(), torch.sigmoid(p["ol"]), p["sh"], vm, K, W, H,
+                                      sh_degree=3, render_mode="RGB+ED", packed=False, tile_size=16, absgrad=True,
+                                      features=p["f"])
+        meta["means2d"].retain_grad()
+        torch.autograd.backward([r, a], [vc, va])
+        torch.cuda.synchronize()
+        out = {k: t.grad.clone() for k, t in p.items()}
+        out["absgrad"] = meta["means2d"].absgrad.clone()
+        return out, meta["flatten_ids"].numel()
+
+    ref, n_isects = grads(POGS_RAST_BWD_MFMA=None, POGS_RAST_BWD_SPLIT=None)
+    assert n_isects > 100 * 3072, n_isects
+    for name, env in (("deferred", dict(POGS_RAST_BWD_MFMA=3)), ("split", dict(POGS_RAST_BWD_MFMA=4)),
+                      ("split on two streams", dict(POGS_RAST_BWD_MFMA=4, POGS_RAST_BWD_SPLIT=1))):
+        got, _ = grads(**dict(dict(POGS_RAST_BWD_SPLIT=None), **env))
+        # Both sides are float32 here, and neither is the oracle.  The vector kernel rebuilds the transmittance from
+        # 1 - alpha of the stored image (as gsplat's backward does): on a pixel saturated to T ~ 1e-4 that start value is
+        # only good to ~6e-4 relative, while the colour kernel of the split form replays T from 1; and two kernels that
+        # round the exponent differently put a Gaussian whose alpha is within an ulp of 1/255 on different sides of the
+        # threshold at a pixel or two (the oracle comparisons flag such pixels; here nothing does).  Hence the wider
+        # margin: measured worst difference 6e-5 of the largest entry.
+        for k in ref:
+            assert_grad_close(got[k], ref[k], f"{k}, {name} against the vector kernel", rtol=2e-3, atol_frac=5e-4)
+
+
 @pytest.mark.parametrize("features,expect", [(32, (2, 2)), (0, (2, 2))])
 def test_planner_selected_large_image_kernels(gpu, tuning, features, expect):
     """No tuning variable involved: at 1024x768 (3072 tiles) the planner itself picks the kernels of a full-size
