@@ -19,7 +19,8 @@ def step():
 out, grads = {}, {}
 for name, env in (("vector", dict(POGS_RAST_BWD_MFMA=1, POGS_RAST_BWD_PPL=None)), ("deferred", dict(POGS_RAST_BWD_MFMA=3, POGS_RAST_BWD_PPL=2)),
                   ("split", dict(POGS_RAST_BWD_MFMA=4, POGS_RAST_BWD_PPL=None)),
-                  ("split, two streams", dict(POGS_RAST_BWD_MFMA=4, POGS_RAST_BWD_PPL=None, POGS_RAST_BWD_SPLIT=1)), ("vector again", dict(POGS_RAST_BWD_MFMA=1, POGS_RAST_BWD_PPL=None, POGS_RAST_BWD_SPLIT=None))):
+                  ("split, two streams", dict(POGS_RAST_BWD_MFMA=4, POGS_RAST_BWD_PPL=None, POGS_RAST_BWD_SPLIT=1)),
+                  ("two streams, vector colour-only kernel", dict(POGS_RAST_BWD_MFMA=1, POGS_RAST_BWD_PPL=None, POGS_RAST_BWD_SPLIT=1)), ("vector again", dict(POGS_RAST_BWD_MFMA=1, POGS_RAST_BWD_PPL=None, POGS_RAST_BWD_SPLIT=None))):
     _lib.set_tuning(**env)
     for _ in range(5): step()
     timer = rendering.StageTimer(only=("pr_raster_bwd", "pr_raster_fwd"))
