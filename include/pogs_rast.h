@@ -205,8 +205,11 @@ int pr_raster_fwd(int C, int N, int D, const float *means2d, const float *conics
 /* v_render_colors[C,H,W,D], v_render_alphas[C,H,W]; render_colors (the forward output) is read only when
  * ed_channel >= 0 and may be NULL otherwise.
  * Out, all zero-filled by the caller and accumulated into with float atomics:
- *   v_geom[C*N,8] = (v_means2d.x, v_means2d.y, v_conic.a, v_conic.b, v_conic.c, v_opacity,
- *                    |v_means2d|.x, |v_means2d|.y)  -- the last two only when absgrad != 0;
+ *   v_geom[C*N,v_geom_ld], columns 0-7 = (v_means2d.x, v_means2d.y, v_conic.a, v_conic.b, v_conic.c, v_opacity,
+ *                    |v_means2d|.x, |v_means2d|.y)  -- the last two only when absgrad != 0; v_geom_ld (0 = 8) is the
+ *                    row pitch in floats: a caller that interleaves the geometry gradients with narrow colour gradients
+ *                    in rows of 16 floats (v_segments pointing into the same rows) gets all of a Gaussian's narrow
+ *                    values delivered as ONE 64-byte atomic request instead of one per tensor;
  *   v_colors[C*N,D] (may be NULL: colour gradients not needed).
  * geom_grad == 0 skips every geometry gradient (v_geom may then be NULL). */
 int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
@@ -214,9 +217,9 @@ int pr_raster_bwd(int C, int N, int D, const float *means2d, const float *conics
                   int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
                   const int32_t *flatten_ids, int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
                   const float *render_colors, int ed_channel, const float *v_render_colors,
-                  const float *v_render_alphas, int absgrad, int geom_grad, float *v_geom, float *v_colors,
-                  const pr_color_segment *segments, const pr_grad_segment *v_segments, int n_segments,
-                  void *stream);
+                  const float *v_render_alphas, int absgrad, int geom_grad, float *v_geom, int v_geom_ld,
+                  float *v_colors, const pr_color_segment *segments, const pr_grad_segment *v_segments,
+                  int n_segments, void *stream);
 
 /* Which kernel variant pr_raster_fwd / pr_raster_bwd pick for a D-channel call over n_tiles_total = C*tile_h*tile_w
  * tiles: pixels per lane (4: one wavefront per 16x16 tile, 2: two, 1: four; always 1 for 8x8 tiles), channels per

@@ -48,7 +48,7 @@ SIGNATURES = {
     "pr_raster_fwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                               c_int64, c_int, _P, _P, _P, _P, c_int, _P]),
     "pr_raster_bwd": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
-                              c_int64, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int, _P]),
+                              c_int64, _P, _P, _P, c_int, _P, _P, c_int, c_int, _P, c_int, _P, _P, _P, c_int, _P]),
     "pr_raster_fwd_plan": (c_int, [c_int, c_int, c_int64, _P, _P, _P]),
     "pr_raster_bwd_plan": (c_int, [c_int, c_int, c_int64, c_int, c_int, _P, _P, _P]),
     "pr_mlp_mask_words": (c_size_t, [c_int64]),

@@ -124,6 +124,12 @@ __device__ __forceinline__ void atomic_add_noret(float *addr, float v) {
   asm volatile("global_atomic_add_f32 %0, %1, off" : : "v"(addr), "v"(v) : "memory");
 }
 
+// The same with a scalar (wave-uniform) base address and a 32-bit byte offset per lane: no 64-bit address arithmetic,
+// and the base costs no vector registers.
+__device__ __forceinline__ void atomic_add_noret_s(float *base, unsigned byte_off, float v) {
+  asm volatile("global_atomic_add_f32 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
+}
+
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;  // smallest alpha the compositor lets contribute
 

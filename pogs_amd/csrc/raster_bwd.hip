@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(64 * WPB) raster_bwd_kernel(
                                        : ((gi == 0 || gi == 1) ? -LN2
                                           : (gi == 2 || gi == 4) ? 0.5f
                                           : (gi == 6 || gi == 7) ? LN2 : 1.f);
-            if (gi < (absgrad ? 8 : 6)) atomic_add_noret(v_geom + (int64_t)gid * 8 + gi, v * sc);
+            if (gi < (absgrad ? 8 : 6)) atomic_add_noret(v_geom + (int64_t)gid * gs.geom_ld + gi, v * sc);
           }
         }
       }
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(64) raster_bwd_geom_mfma_kernel(
     const int32_t *__restrict__ tile_order, const int32_t *__restrict__ flatten_ids, int n_isects,
     const float *__restrict__ render_alphas, const int32_t *__restrict__ last_ids,
     const float *__restrict__ render_colors, int ed_channel, const float *__restrict__ v_render_colors,
-    const float *__restrict__ v_render_alphas, int absgrad, float *__restrict__ v_geom) {
+    const float *__restrict__ v_render_alphas, int absgrad, float *__restrict__ v_geom, int geom_ld) {
   using Rg = Region<16, 1>;
   constexpr int ROW = color_row(CD), CDP = round4(CD), BS = 32;
   constexpr int KS = CDP / 16, CM = 16 * KS, CV = CDP - CM;  // k steps / channels on the matrix cores / on the VALU
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(64) raster_bwd_geom_mfma_kernel(
         const float4 p0 = own[0], p1 = own[1], p2 = own[2], p3 = own[3];
         const float tot = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w)) +
                           ((p2.x + p2.y) + (p2.z + p2.w)) + ((p3.x + p3.y) + (p3.z + p3.w));
-        if (lane < n_geo) atomic_add_noret(v_geom + (int64_t)gid * 8 + lane, tot * gscale);
+        if (lane < n_geo) atomic_add_noret(v_geom + (int64_t)gid * geom_ld + lane, tot * gscale);
       }
     }
   }
@@ -600,13 +600,13 @@ static int launch_bwd_geom_mfma(int C, int N, int D, const float *means2d, const
                                 const int32_t *flatten_ids, int64_t n_isects, const float *render_alphas,
                                 const int32_t *last_ids, const float *render_colors, int ed_channel,
                                 const float *v_render_colors, const float *v_render_alphas, int absgrad, float *v_geom,
-                                hipStream_t stream) {
+                                int geom_ld, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<16, 1>::WPT;
   const unsigned grid = region_grid(n_regions, Region<16, 1>::WPT, tile_order != nullptr);
   hipLaunchKernelGGL((raster_bwd_geom_mfma_kernel<CD>), dim3(grid), dim3(64), 0, stream, (int)n_regions,
                      N, D, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
                      tile_order, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel,
-                     v_render_colors, v_render_alphas, absgrad, v_geom);
+                     v_render_colors, v_render_alphas, absgrad, v_geom, geom_ld);
   return check_launch("raster_bwd_geom_mfma_kernel");
 }
 
@@ -875,7 +875,7 @@ __global__ void __launch_bounds__(64) raster_bwd_full_mfma_kernel(
         const float4 p0 = own[0], p1 = own[1], p2 = own[2], p3 = own[3];
         const float tot = ((p0.x + p0.y) + (p0.z + p0.w)) + ((p1.x + p1.y) + (p1.z + p1.w)) +
                           ((p2.x + p2.y) + (p2.z + p2.w)) + ((p3.x + p3.y) + (p3.z + p3.w));
-        if (lane < n_geo) atomic_add_noret(v_geom + (int64_t)gid * 8 + lane, tot * gscale);
+        if (lane < n_geo) atomic_add_noret(v_geom + (int64_t)gid * gs.geom_ld + lane, tot * gscale);
         if (CR > 0 && lane >= 8 && rcol) atomic_add_noret(rcol + (int64_t)(rshared ? gid - cam_first : gid) * rld, tot);
       }
     }
@@ -1022,7 +1022,7 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
                              const int32_t *flatten_ids, int64_t n_isects, const float *render_alphas,
                              const int32_t *last_ids, const float *render_colors, int ed_channel,
                              const float *v_render_colors, const float *v_render_alphas, int absgrad, int geom_grad,
-                             float *v_geom, float *v_colors, const pr_color_segment *segments,
+                             float *v_geom, int v_geom_ld, float *v_colors, const pr_color_segment *segments,
                              const pr_grad_segment *v_segments, int n_segments, void *stream) {
   if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)
     return PR_EINVAL;
@@ -1039,6 +1039,8 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
   int rcs = make_color_segs(colors, D, segments, n_segments, true, cs);
   if (!rcs) rcs = make_grad_segs(v_colors, D, v_segments, n_segments, gs);
   if (rcs) return rcs;
+  if (v_geom_ld != 0 && v_geom_ld < 8) return PR_EINVAL;
+  gs.geom_ld = v_geom_ld ? v_geom_ld : 8;
   for (int i = 0; i < gs.n; ++i)
     if (n_segments > 0 && (gs.begin[i] != cs.begin[i])) return PR_EINVAL;  // widths must match the colours'
   bool any_color_grad = false;
@@ -1065,12 +1067,24 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
     const int rc = pr_raster_bwd(C, N, D, means2d, conics, colors, opacities, backgrounds, width, height, tile_size,
                                  tile_w, tile_h, isect_offsets, tile_order, flatten_ids, n_isects, render_alphas,
                                  last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas, absgrad, 1, v_geom,
-                                 nullptr, segments, none, n_segments, stream);
+                                 v_geom_ld, nullptr, segments, none, n_segments, stream);
     if (rc) return rc;
     return launch_bwd_colour_mfma(C, N, D, means2d, conics, opacities, width, height, tile_w, tile_h, isect_offsets,
                                   tile_order, flatten_ids, render_alphas, last_ids, ed_channel, v_render_colors, gs,
                                   (hipStream_t)stream);
   }
+  // geometry (+ colour) gradients with both contractions on the float32 matrix cores, 8x8 pixel regions
+  // (it addresses rows with 32-bit byte offsets from each tensor's base)
+  bool small_tensors = (int64_t)C * N * gs.geom_ld * 4 < (1ll << 32);
+  for (int i = 0; i < cs.n; ++i) {
+    small_tensors = small_tensors && (int64_t)C * N * cs.ld[i] * 4 < (1ll << 32);
+    small_tensors = small_tensors && (int64_t)C * N * gs.ld[i] * 4 < (1ll << 32);
+  }
+  if (geom_grad && tuning().bwd_mfma == 5 && small_tensors && bwd_mm_supports(pick_chunk(D), tile_size))
+    return launch_bwd_mm(pick_chunk(D), tile_size, any_color_grad, C, N, D, means2d, conics, cs, opacities, backgrounds,
+                         width, height, tile_w, tile_h, isect_offsets, tile_order, flatten_ids, n_isects,
+                         render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas, absgrad,
+                         v_geom, gs, (hipStream_t)stream);
   const BwdPlan plan = plan_bwd(D, geom_grad, any_color_grad, tile_size, (int64_t)C * tile_w * tile_h);
   // geometry gradients only, 16x16 tiles at 1 pixel per lane: the dot products go to the matrix cores
   if (geom_grad && !any_color_grad && tile_size == 16 && plan.ppl == 1 && tuning().bwd_mfma != 0) {
@@ -1078,7 +1092,7 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
 #define GEOM_MFMA_ARGS                                                                                             \
   C, N, D, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets, tile_order, \
       flatten_ids, n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas, \
-      absgrad, v_geom, (hipStream_t)stream
+      absgrad, v_geom, gs.geom_ld, (hipStream_t)stream
     switch (cd) {
       case 16: return launch_bwd_geom_mfma<16>(GEOM_MFMA_ARGS);
       case 24: return launch_bwd_geom_mfma<24>(GEOM_MFMA_ARGS);

@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(64, 2) raster_bwd_cmfma_kernel(
         if (lane < CR) {
           if (rcol) atomic_add_noret(rcol + (int64_t)(rshared ? gid - cam_first : gid) * rld, v);
         } else if (gi < n_geo) {
-          atomic_add_noret(v_geom + (int64_t)gid * 8 + gi, v * gscale);
+          atomic_add_noret(v_geom + (int64_t)gid * gs.geom_ld + gi, v * gscale);
         }
       }
       if (++nrows == RW) {

@@ -133,8 +133,12 @@ struct ColorSegs {
 struct GradSegs {  // same layout for the colour gradients; ptr NULL = this segment needs no gradient
   float *ptr[3];
   int begin[3], ld[3], shared[3], n;
+  int geom_ld;  // row pitch (floats) of the packed geometry gradients v_geom[C*N, geom_ld]: 8, or more when the caller
+                // interleaves them with narrow colour gradients so that one Gaussian's values share a 64-byte segment
 };
 
+inline void set_geom_ld(ColorSegs &) {}
+inline void set_geom_ld(GradSegs &g) { g.geom_ld = 8; }
 // Host side: the kernels' segment tables from the C-ABI arguments.  Without segments the single [C,N,D]
 // tensor is segment 0.  Widths must be positive and add up to D.
 template <class Segs, class Ptr, class AbiSeg>
@@ -146,6 +150,7 @@ inline int make_segs(Ptr whole, int D, const AbiSeg *segments, int n_segments, b
     out.ld[i] = 0;
     out.shared[i] = 0;
   }
+  set_geom_ld(out);
   if (n_segments < 0 || n_segments > 3) return PR_EINVAL;
   if (n_segments == 0) {
     if (need_ptrs && !whole && !null_ok) return PR_EINVAL;
@@ -194,6 +199,17 @@ int launch_bwd_colour_mfma(int C, int N, int D, const float *means2d, const floa
                            const int32_t *tile_order, const int32_t *flatten_ids, const float *render_alphas,
                            const int32_t *last_ids, int ed_channel, const float *v_render_colors, const GradSegs &gs,
                            hipStream_t stream);
+
+// raster_bwd_mm.hip: backward with both channel contractions on the float32 matrix cores, one wavefront per 8x8
+// pixel region (geometry gradients wanted; colour gradients optional)
+bool bwd_mm_supports(int cd, int tile_size);
+int launch_bwd_mm(int cd, int tile_size, bool color_grad, int C, int N, int D, const float *means2d,
+                  const float *conics, const ColorSegs &cs, const float *opacities, const float *backgrounds,
+                  int width, int height, int tile_w, int tile_h, const int32_t *isect_offsets,
+                  const int32_t *tile_order, const int32_t *flatten_ids, int64_t n_isects,
+                  const float *render_alphas, const int32_t *last_ids, const float *render_colors, int ed_channel,
+                  const float *v_render_colors, const float *v_render_alphas, int absgrad, float *v_geom,
+                  const GradSegs &gs, hipStream_t stream);
 
 // The geometry of one batch of up to 64 intersections, one per lane, loaded ahead of time: the ids and the
 // records they point to are two dependent global round trips, which the caller issues a whole batch early

@@ -255,7 +255,7 @@ class _SphericalHarmonics(torch.autograd.Function):
         return None, v_means, v_campos, (v_coeffs if ctx.needs_input_grad[3] else None), None, None
 
 
-_ORDER_MIN_TILES = 2048  # fewer tiles than wave slots: nothing to balance
+_ORDER_MIN_TILES = int(os.environ.get("POGS_RAST_ORDER_MIN_TILES", "2048"))  # fewer tiles than wave slots: nothing to balance
 _ASYNC_DEPTH_ORDER_MIN = 100_000
 # POGS_RAST_BINNING=lists builds the per-tile lists with per-tile counters and one LDS sort per tile instead of the
 # two-level device sort.  Measured at 1M Gaussians / 1080p it is SLOWER (0.66 ms against 0.50 ms): 6.4M scattered
@@ -653,12 +653,31 @@ def _split_backward(D: int, tile_size: int) -> bool:
 def _grad_targets(parts, want, geom, C, N, dev):
     """Zero-filled accumulation targets of the backward compositor: the packed geometry gradients [C*N,8] and the
     narrow colour parts (rgb, depth) share one allocation and one fill; wide parts (features) get their own.
-    -> (v_geom or None, [gradient buffer or None per part])."""
+    -> (v_geom or None, its row pitch, [gradient buffer or None per part], [row pitch per part]).
+
+    When the per-camera narrow parts fit beside the eight geometry values in a row of 16 floats, the pool is that
+    table of rows, [C*N,16] = (geometry 0-7 | narrow parts | padding): the memory system delivers float atomics one
+    aligned 64-byte segment at a time (about 21 G segments/s on an MI355X whatever they carry), and all of a
+    Gaussian's narrow gradients then travel as one request instead of one per tensor.  The views handed out are
+    row-strided; pr_sh_bwd / pr_project_bwd take row pitches."""
+    narrow = [w and p.shape[-1] <= 4 and p.dim() == 3 for w, p in zip(want, parts)]
+    if geom and any(narrow) and 8 + sum(p.shape[-1] for p, k in zip(parts, narrow) if k) <= 16:
+        rows = torch.zeros(C, N, 16, dtype=torch.float32, device=dev)
+        at, v_parts, lds = 8, [], []
+        for p, w, k in zip(parts, want, narrow):
+            if k:
+                v_parts.append(rows[..., at:at + p.shape[-1]])
+                lds.append(16)
+                at += p.shape[-1]
+            else:
+                v_parts.append(torch.zeros_like(p) if w else None)
+                lds.append(p.shape[-1])
+        return rows[..., :8], 16, v_parts, lds
     pooled = [w and p.shape[-1] <= 4 for w, p in zip(want, parts)]
     n_pool = (C * N * 8 if geom else 0) + sum((p.numel() + 7) // 8 * 8 for p, k in zip(parts, pooled) if k)
     pool = torch.zeros(n_pool, dtype=torch.float32, device=dev) if n_pool else None
     at = C * N * 8 if geom else 0
-    v_geom = pool[:at].view(C * N, 8) if geom else None
+    v_geom = pool[:at].view(C, N, 8) if geom else None
     v_parts = []
     for p, w, k in zip(parts, want, pooled):
         if not w:
@@ -668,7 +687,7 @@ def _grad_targets(parts, want, geom, C, N, dev):
             at += (p.numel() + 7) // 8 * 8
         else:
             v_parts.append(torch.zeros_like(p))
-    return v_geom, v_parts
+    return v_geom, 8, v_parts, [p.shape[-1] for p in parts]
 
 
 class _Rasterize(torch.autograd.Function):
@@ -734,7 +753,7 @@ class _Rasterize(torch.autograd.Function):
             main = torch.cuda.current_stream(dev)
             side = _state.side_stream(dev, main)
             with torch.cuda.stream(side):
-                v_geom, v_parts = _grad_targets(parts, want, geom, C, N, dev)
+                v_geom, geom_ld, v_parts, v_lds = _grad_targets(parts, want, geom, C, N, dev)
                 filled = torch.cuda.Event()
                 filled.record(side)
             main.wait_event(filled)
@@ -742,21 +761,23 @@ class _Rasterize(torch.autograd.Function):
                 if t is not None:
                     t.record_stream(main)
         else:
-            v_geom, v_parts = _grad_targets(parts, want, geom, C, N, dev)
+            v_geom, geom_ld, v_parts, v_lds = _grad_targets(parts, want, geom, C, N, dev)
         if geom or any(v is not None for v in v_parts):
-            single = len(parts) == 1 and not items[0][3]
+            single = len(parts) == 1 and not items[0][3] and v_lds[0] == items[0][1]
             keep_c, segs = (None, None) if single else _lib.segment_array(items)
 
             def launch(geom_flag, vg, vps):
                 keep_g, vsegs = (None, None) if single else _lib.segment_array(
-                    [(None if v is None else v.data_ptr(), w, ld, sh) for v, (_, w, ld, sh) in zip(vps, items)])
+                    [(None if v is None else v.data_ptr(), w, vld, sh)
+                     for v, vld, (_, w, _ld, sh) in zip(vps, v_lds, items)])
                 with torch.cuda.device(dev):
                     _call("pr_raster_bwd", C, N, D, _ptr(means2d), _ptr(conics), _ptr(parts[0]) if single else None,
                           _ptr(opacities), _ptr(backgrounds), width, height, tile_size, tw, th, _ptr(isect_offsets),
                           _ptr(tile_order), _ptr(flatten_ids), flatten_ids.numel(), _ptr(render_alphas),
                           _ptr(last_ids), _ptr(render_colors), ed_channel, _ptr(v_render_colors),
                           _ptr(v_render_alphas), int(absgrad), int(geom_flag), _ptr(vg),
-                          _ptr(vps[0]) if single else None, segs, vsegs, 0 if single else len(items), _stream())
+                          geom_ld, _ptr(vps[0]) if single else None, segs, vsegs,
+                          0 if single else len(items), _stream())
                 del keep_g
 
             if geom and any(v is not None for v in v_parts) and _split_backward(D, tile_size):
@@ -778,7 +799,7 @@ class _Rasterize(torch.autograd.Function):
             del keep_c
         v_means2d = v_conics = v_opacities = None
         if geom:
-            g = v_geom.view(C, N, 8)
+            g = v_geom
             v_means2d, v_conics, v_opacities = g[..., 0:2], g[..., 2:5], g[..., 5]
             if absgrad:
                 ctx.means2d_obj.absgrad = g[..., 6:8]

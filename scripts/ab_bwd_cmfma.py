@@ -17,10 +17,12 @@ def step():
     r, a, _ = rendering.rasterization(p["means"], p["quats"], p["ls"].exp(), torch.sigmoid(p["ol"]), p["sh"], vm, K, W, H, sh_degree=3, render_mode="RGB+ED", packed=False, tile_size=16, absgrad=True, features=p["f"])
     torch.autograd.backward([r, a], [vc, va])
 out, grads = {}, {}
-for name, env in (("vector", dict(POGS_RAST_BWD_MFMA=1, POGS_RAST_BWD_PPL=None)), ("deferred", dict(POGS_RAST_BWD_MFMA=3, POGS_RAST_BWD_PPL=2)),
+VARIANTS = os.environ.get("AB_VARIANTS", "").split(",") if os.environ.get("AB_VARIANTS") else None
+for name, env in (("vector", dict(POGS_RAST_BWD_MFMA=1, POGS_RAST_BWD_PPL=None)), ("mm", dict(POGS_RAST_BWD_MFMA=5, POGS_RAST_BWD_PPL=None)), ("deferred", dict(POGS_RAST_BWD_MFMA=3, POGS_RAST_BWD_PPL=2)),
                   ("split", dict(POGS_RAST_BWD_MFMA=4, POGS_RAST_BWD_PPL=None)),
                   ("split, two streams", dict(POGS_RAST_BWD_MFMA=4, POGS_RAST_BWD_PPL=None, POGS_RAST_BWD_SPLIT=1)),
                   ("two streams, vector colour-only kernel", dict(POGS_RAST_BWD_MFMA=1, POGS_RAST_BWD_PPL=None, POGS_RAST_BWD_SPLIT=1)), ("vector again", dict(POGS_RAST_BWD_MFMA=1, POGS_RAST_BWD_PPL=None, POGS_RAST_BWD_SPLIT=None))):
+    if VARIANTS and name not in VARIANTS: continue
     _lib.set_tuning(**env)
     for _ in range(5): step()
     timer = rendering.StageTimer(only=("pr_raster_bwd", "pr_raster_fwd"))
@@ -39,5 +41,5 @@ for name, env in (("vector", dict(POGS_RAST_BWD_MFMA=1, POGS_RAST_BWD_PPL=None))
     print(name, json.dumps(out[name]), flush=True)
 for k in p:
     a = grads["vector"][k]
-    print(k, "max |diff| / max |ref| =", [float((a - grads[n][k]).abs().max() / a.abs().max()) for n in ("deferred", "split", "split, two streams")])
+    print(k, "max |diff| / max |ref| =", {n: float((a - grads[n][k]).abs().max() / a.abs().max()) for n in grads if n != "vector"})
 _lib.set_tuning(POGS_RAST_BWD_MFMA=None, POGS_RAST_BWD_PPL=None)

@@ -707,6 +707,64 @@ def test_rasterization_end_to_end_with_matrix_core_backward(gpu, tuning):
     assert_grad_close(a["viewmats"].grad[:, :3, :], b["viewmats"].grad[:, :3, :], "viewmats")
 
 
+@pytest.mark.parametrize("D", [4, 19, 32, 36, 33, 48, 64])
+@pytest.mark.parametrize("tile_size", [16, 8])
+@pytest.mark.parametrize("grads", ["geometry+colours", "geometry"])
+def test_raster_backward_float32_matrix_core_contractions(gpu, tuning, D, tile_size, grads):
+    """raster_bwd_mm_kernel (POGS_RAST_BWD_MFMA=5): one wavefront per 8x8 pixel region, S = <colour, v> and the
+    colour-gradient contraction sum_p fac * v as float32 matrix products (v_mfma_f32_16x16x4_f32: exact float32
+    products), list entries compacted into a ring and walked 16 at a time; against the float64 oracle, |v_xy| against
+    the float32 C restatement.  Tile lists run from a handful of entries to several ring refills."""
+    rd = _rendering()
+    from oracle import raster_c as RC
+
+    cgrad = grads != "geometry"
+    tuning(POGS_RAST_BWD_MFMA=5)
+    sc = small_scene(n=600, w=70, h=45, views=2, seed=4, lo=0.02, hi=0.3)
+    dev, offs, flat = _staged(gpu, sc, D, tile_size)
+    bg = torch.rand(2, D, generator=torch.Generator().manual_seed(9)).to(gpu) if D in (19, 36, 64) else None
+    cpu, out_r, alpha_r, amb = _oracle_raster(dev, offs, flat, sc, tile_size, bg, True)
+    g = torch.Generator().manual_seed(13)
+    keep = (~amb)[..., None].float()
+    vc, va = torch.randn(out_r.shape, generator=g) * keep, torch.randn(alpha_r.shape, generator=g) * keep
+    (out_r * vc.double()).sum().add((alpha_r * va.double()).sum()).backward()
+    leaves = {k: v.clone().requires_grad_(cgrad or k != "colors") for k, v in dev.items()}
+    out, alpha = rd.rasterize_to_pixels(leaves["means2d"], leaves["conics"], leaves["colors"], leaves["opacities"],
+                                        sc.width, sc.height, tile_size, offs, flat, backgrounds=bg, absgrad=True)
+    ((out * vc.to(gpu)).sum() + (alpha * va.to(gpu)).sum()).backward()
+    for k in (["colors"] if cgrad else []) + ["opacities", "conics", "means2d"]:
+        assert_grad_close(leaves[k].grad, cpu[k].grad, f"{k} D={D} ts={tile_size} float32 matrix-core backward")
+    o32, a32, last = RC.raster_fwd(dev["means2d"].cpu(), dev["conics"].cpu(), dev["colors"].cpu(),
+                                   dev["opacities"].cpu(), sc.width, sc.height, tile_size, offs.cpu(), flat.cpu(),
+                                   backgrounds=None if bg is None else bg.cpu())
+    _, v_abs, _, _, _ = RC.raster_bwd(dev["means2d"].cpu(), dev["conics"].cpu(), dev["colors"].cpu(),
+                                      dev["opacities"].cpu(), sc.width, sc.height, tile_size, offs.cpu(), flat.cpu(), a32,
+                                      last, vc, va, backgrounds=None if bg is None else bg.cpu())
+    assert_grad_close(leaves["means2d"].absgrad, v_abs, f"absgrad D={D}", rtol=2e-3, atol_frac=2e-4)
+
+
+def test_rasterization_end_to_end_with_float32_matrix_core_backward(gpu, tuning):
+    """The whole call at the training step's channel layout ([rgb from SH | 32 features | expected depth], gathered
+    from three tensors, gradients scattered into three) with raster_bwd_mm_kernel."""
+    rd = _rendering()
+    tuning(POGS_RAST_BWD_MFMA=5)
+    sc = small_scene(n=500, w=70, h=45, views=2, seed=8, lo=0.02, hi=0.3, f=32)
+    kw = dict(sh_degree=3, render_mode="RGB+ED", tile_size=16, packed=False, absgrad=True)
+    a = scene_args(sc, device=gpu, requires_grad=True)
+    out, alpha, meta = rd.rasterization(**a, **kw)
+    b = scene_args(sc, dtype=torch.float64, requires_grad=True)
+    out_r, alpha_r, meta_r = R.rasterization(**b, **kw, radii_override=meta["radii"].cpu())
+    amb = meta_r["ambiguous"]
+    g = torch.Generator().manual_seed(21)
+    keep = (~amb)[..., None].float()
+    vc, va = torch.randn(out_r.shape, generator=g) * keep, torch.randn(alpha_r.shape, generator=g) * keep
+    ((out * vc.to(gpu)).sum() + (alpha * va.to(gpu)).sum()).backward()
+    (out_r * vc.double()).sum().add((alpha_r * va.double()).sum()).backward()
+    for k in ("means", "quats", "scales", "opacities", "colors", "features"):
+        assert_grad_close(a[k].grad, b[k].grad, k)
+    assert_grad_close(a["viewmats"].grad[:, :3, :], b["viewmats"].grad[:, :3, :], "viewmats")
+
+
 @pytest.mark.parametrize("D", [32, 36, 33])
 @pytest.mark.parametrize("with_bg", [False, True])
 def test_raster_backward_deferred_colour_gradient_on_matrix_cores(gpu, tuning, D, with_bg):
