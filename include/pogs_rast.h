@@ -161,7 +161,11 @@ int pr_depth_order(int C, int N, const float *depths, int32_t *depth_order, void
  * storage) lives in a 24 MiB device array inside the library instead of a caller-supplied buffer; the call
  * allocates and frees nothing.  Limit: C*N <= pr_depth_order_static_max() (about 1.25 million on MI355X: the 1M-Gaussian training shape fits); larger inputs
  * return PR_EUNSUPPORTED with the reason in pr_last_hip_error().  Every call on one GPU uses that GPU's one array:
- * calls that overlap on one GPU (two streams, two threads) race -- serialise them or use pr_depth_order. */
+ * calls that overlap on one GPU (two streams, two threads) race -- serialise them or use pr_depth_order.
+ * The FIRST call on each device looks the array's address up (hipGetSymbolAddress, under a lock): make that call
+ * outside stream capture, e.g. once at start-up with N = 1; later calls on that device only launch kernels.  With
+ * POGS_RAST_DEPTH_SORT=2 (the sample sort, a tuning aid) the call also sets a kernel attribute and must not be
+ * captured at all. */
 int64_t pr_depth_order_static_max(void);
 int pr_depth_order_static(int C, int N, const float *depths, int32_t *depth_order, void *stream);
 /* isect_offsets[C,tile_h,tile_w] int32: index of the first intersection of every (camera, tile). */

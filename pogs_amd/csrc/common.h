@@ -41,10 +41,12 @@ struct Tuning {
   int fwd_chunk;    // POGS_RAST_FWD_CHUNK: widest forward channel pass (0 = planner)
   int fwd_mfma;     // POGS_RAST_FWD_MFMA: 1 = split-bf16 matrix-core colour accumulation for 32..72-channel passes
   int bwd_ppl;      // POGS_RAST_BWD_PPL: as fwd_ppl for the backward compositor
-  int bwd_mfma;     // POGS_RAST_BWD_MFMA: 0 = vector kernels only; 1 (default) = matrix-core dot products in the geometry-only
-                    // backward at 1 pixel per lane; 2 = both contractions on the matrix cores at 1 pixel per lane;
-                    // 3 = deferred matrix-core colour gradient at 2 pixels per lane (32/36-channel passes);
-                    // 4 = colour gradients in a kernel of their own on the matrix cores (up to 48 channels)
+  int bwd_mfma;     // POGS_RAST_BWD_MFMA: -1 (unset) = planner: the float32 matrix-core kernel on 8x8 regions wherever it wins,
+                    // the bf16 matrix-core dot products for what is left of the geometry-only backward at 1 pixel per lane;
+                    // 0 = vector kernels only; 1 = as -1 without the float32 matrix-core kernel; 2 = both contractions as
+                    // split-bf16 matrix products at 1 pixel per lane; 3 = deferred split-bf16 colour gradient at 2 pixels
+                    // per lane (32/36-channel passes); 4 = colour gradients in a split-bf16 kernel of their own (up to 48
+                    // channels); 5 = the float32 matrix-core kernel for every call it is built for
   int mlp_variant;  // POGS_MLP_VARIANT: -1 = default
   int depth_sort;   // POGS_RAST_DEPTH_SORT: 0 = chained-scan radix sort (onesweep.h), 1 = rocPRIM's radix sort for both binning
                     // sorts, 2 = sample sort of the depth keys between 32 K and 1.25 M Gaussians
@@ -125,9 +127,19 @@ __device__ __forceinline__ void atomic_add_noret(float *addr, float v) {
 }
 
 // The same with a scalar (wave-uniform) base address and a 32-bit byte offset per lane: no 64-bit address arithmetic,
-// and the base costs no vector registers.
+// and the base costs no vector registers.  The `s_nop 4` is part of the instruction's contract here: a vector-memory
+// instruction must not read a scalar register within five wait states of a VECTOR instruction writing it
+// (v_readlane_b32 restoring a spilled base, v_readfirstlane_b32), and the compiler's hazard pass, which inserts those
+// wait states for its own instructions, does not look inside inline assembly -- without it the access can go out
+// with a stale half of the base address.
 __device__ __forceinline__ void atomic_add_noret_s(float *base, unsigned byte_off, float v) {
-  asm volatile("global_atomic_add_f32 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
+  asm volatile("s_nop 4\n\tglobal_atomic_add_f32 %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
+}
+// For values that come straight out of matrix instructions: the hazard pass also does not know that the inline
+// assembly above reads them, and a vector-memory read of a matrix result needs up to 18 wait states after the
+// instruction that produces it.
+__device__ __forceinline__ void settle_mfma_results() {
+  asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 }
 
 constexpr float LOG2E = 1.4426950408889634f;

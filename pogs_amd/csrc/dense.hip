@@ -229,6 +229,7 @@ __global__ void __launch_bounds__(256) dense_wgrad_kernel(int64_t P, int N, int 
     }
   }
   // result tile t: row = n0 + 32 wave + (r & 3) + 8 (r >> 2) + 4 kh, column = k0 + 32 t + m
+  settle_mfma_results();
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -273,7 +274,8 @@ __global__ void __launch_bounds__(256) l2norm_bwd_kernel(int64_t P, int N, const
     dot += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
   }
   dot = wave_sum_all(dot);
-  const float n = norms[row], inv = 1.f / (n + eps), c = dot * inv * inv / n;
+  // at the zero vector the norm's subgradient is taken as 0 (as torch does): dy = g / eps, finite for eps > 0
+  const float n = norms[row], inv = 1.f / (n + eps), c = n > 0.f ? dot * inv * inv / n : 0.f;
   float4 *dst = reinterpret_cast<float4 *>(dy + row * N);
   for (int i = lane; i < N / 4; i += 64) {
     const float4 a = ys[i], b = gs[i];

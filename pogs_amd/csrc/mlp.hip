@@ -459,6 +459,7 @@ __global__ void __launch_bounds__(256, 1) mlp_bwd_full_kernel(int64_t P, const f
     }
   }
   // result tile (mo, no): row = out feature 32 mo + (r&3) + 8 (r>>2) + 4 kh, column = in feature 32 no + m
+  settle_mfma_results();
 #pragma unroll
   for (int l = 0; l < LAYERS; ++l)
 #pragma unroll

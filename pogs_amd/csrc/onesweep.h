@@ -215,6 +215,11 @@ __global__ void __launch_bounds__(THREADS) pass_kernel(KeyFn keys_in, ValFn vals
     const uint32_t prev = wave_cnt[w][d];
     if (lane == 63 - __builtin_clzll(m)) wave_cnt[w][d] = prev + (uint32_t)__builtin_popcountll(m);
     rank[r] = prev + below;
+    // the next round reads what this round's leader lanes stored: keep the LDS accesses of the unrolled rounds in
+    // program order (a wavefront's LDS operations complete in issue order; this stops the compiler moving them)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   __syncthreads();
 

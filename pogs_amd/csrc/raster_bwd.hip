@@ -896,6 +896,7 @@ __global__ void __launch_bounds__(64) raster_bwd_full_mfma_kernel(
         acc = mfma_bf16(ah, vbl[nt][s4], acc);
       }
       float *dst = mcol[nt];
+      settle_mfma_results();
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int slot = (r & 3) + 8 * (r >> 2) + 4 * mh;
@@ -953,6 +954,21 @@ struct BwdPlan {
   int ppl, per;
 };
 
+// Does the call go to raster_bwd_mm_kernel (8x8 pixel regions, channel contractions as float32 matrix products)?
+// POGS_RAST_BWD_MFMA=5 forces it wherever it is built; unset, it takes every call except narrow passes (up to 8
+// channels) on 16x16 tiles with geometry gradients -- with so few channels the contractions are a small part of an
+// iteration and the vector kernel's larger regions (half tiles) win: measured at 1M Gaussians, 1080p, 4 channels
+// 0.51 ms against 0.62; at 36 channels 1.19 against 1.02, at 64 channels on a 450x250 image 0.98 against 0.33.  Any
+// other value of the variable, or a forced pixels-per-lane count, keeps the older kernels (tests, A/B runs).
+static bool plan_mm(int D, int tile_size, int geom_grad) {
+  const int cd = pick_chunk(D);
+  if (cd < 0 || !bwd_mm_supports(cd, tile_size)) return false;
+  const int mode = tuning().bwd_mfma;
+  if (mode == 5 || mode == 6) return true;   // 6: as 5 with geometry and colour gradients as separate launches
+  if (mode != -1 || tuning().bwd_ppl != 0) return false;
+  return !(tile_size == 16 && cd <= 8 && geom_grad);
+}
+
 // Geometry gradients need the dot product over ALL channels in one pass; colour-only gradients can be
 // chunked freely (narrow chunks keep 4 pixels per lane).  POGS_RAST_BWD_PPL overrides (tuning aid).
 static BwdPlan plan_bwd(int D, int geom_grad, bool color_grad, int tile_size, int64_t n_tiles_total) {
@@ -994,9 +1010,15 @@ extern "C" int pr_raster_bwd_plan(int D, int tile_size, int64_t n_tiles_total, i
   const BwdPlan plan = plan_bwd(D, geom_grad, color_grad != 0, tile_size, n_tiles_total);
   if (pixels_per_lane) *pixels_per_lane = plan.ppl;
   if (channels_per_pass) *channels_per_pass = plan.per;
+  if (plan_mm(D, tile_size, geom_grad)) {
+    if (pixels_per_lane) *pixels_per_lane = 1;
+    if (channels_per_pass) *channels_per_pass = geom_grad ? D : min(D, 48);
+    if (matrix_cores) *matrix_cores = 1;
+    return PR_OK;
+  }
   if (matrix_cores) {
     const int cd = pick_chunk(D);
-    const int mode = tuning().bwd_mfma;
+    const int mode = tuning().bwd_mfma == -1 ? 1 : tuning().bwd_mfma;
     *matrix_cores = (geom_grad && !color_grad && tile_size == 16 && plan.ppl == 1 && mode != 0 && cd >= 16 && cd <= 72) ||
                     (geom_grad && color_grad && tile_size == 16 && mode == 2 && plan.per == D && (cd == 32 || cd == 36 || cd == 64 || cd == 72)) ||
                     (geom_grad && color_grad && tile_size == 16 && mode == 3 && plan.per == D && plan.ppl == 2 && (cd == 32 || cd == 36)) ||
@@ -1080,14 +1102,14 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
     small_tensors = small_tensors && (int64_t)C * N * cs.ld[i] * 4 < (1ll << 32);
     small_tensors = small_tensors && (int64_t)C * N * gs.ld[i] * 4 < (1ll << 32);
   }
-  if (geom_grad && tuning().bwd_mfma == 5 && small_tensors && bwd_mm_supports(pick_chunk(D), tile_size))
-    return launch_bwd_mm(pick_chunk(D), tile_size, any_color_grad, C, N, D, means2d, conics, cs, opacities, backgrounds,
+  if (small_tensors && plan_mm(D, tile_size, geom_grad))
+    return launch_bwd_mm(pick_chunk(D), tile_size, geom_grad != 0, any_color_grad, tuning().bwd_mfma == 6, C, N, D, means2d, conics, cs, opacities, backgrounds,
                          width, height, tile_w, tile_h, isect_offsets, tile_order, flatten_ids, n_isects,
                          render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas, absgrad,
                          v_geom, gs, (hipStream_t)stream);
   const BwdPlan plan = plan_bwd(D, geom_grad, any_color_grad, tile_size, (int64_t)C * tile_w * tile_h);
   // geometry gradients only, 16x16 tiles at 1 pixel per lane: the dot products go to the matrix cores
-  if (geom_grad && !any_color_grad && tile_size == 16 && plan.ppl == 1 && tuning().bwd_mfma != 0) {
+  if (geom_grad && !any_color_grad && tile_size == 16 && plan.ppl == 1 && tuning().bwd_mfma != 0) {  // (-1 included)
     const int cd = pick_chunk(D);
 #define GEOM_MFMA_ARGS                                                                                             \
   C, N, D, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets, tile_order, \

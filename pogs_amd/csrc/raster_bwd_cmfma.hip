@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(64, 2) raster_bwd_cmfma_kernel(
         acc[n] = mfma16_bf16(ah, vbl[n][s], acc[n]);
       }
     }
+    settle_mfma_results();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int g = __shfl(row_gid, 4 * lg + r);
@@ -492,6 +493,7 @@ __global__ void __launch_bounds__(64, 3) raster_bwd_colour_mfma_kernel(
         acc[n] = mfma16_bf16(ah, vbl[n][s], acc[n]);
       }
     }
+    settle_mfma_results();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int g = __shfl(row_gid, 4 * lg + r);

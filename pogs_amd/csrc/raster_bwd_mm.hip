@@ -34,37 +34,52 @@ constexpr int MM_GP = 4;    // contributing iterations whose geometry totals are
 constexpr int MM_RW = 16;   // rows of a chunk / of the fac image
 constexpr int MM_SP = 68;   // row pitch (floats) of the S table and the fac image
 
-template <bool CGRAD>
+template <bool GEOM, bool CGRAD>
 struct alignas(16) MmLds {
   float4 ra[MM_QN];  // x, y, opacity, A' (= -0.5 a log2e)
   float4 rb[MM_QN];  // B' (= -b log2e), C' (= -0.5 c log2e), flat Gaussian index, list position (both as bits)
   union {
     struct {
-      float sbuf[MM_RW * MM_SP];                // S[slot][pixel]
+      float sbuf[GEOM ? MM_RW * MM_SP : 4];     // S[slot][pixel]
       float fimg[CGRAD ? MM_RW * MM_SP : 4];    // fac[row][pixel]
     } w;
     float tr[64 * 20];  // prologue: 16 channels of the region's cotangents, pixel-major, for the two operand layouts
   } u;
-  float red[MM_GP * 2 * 68];  // lane-swap folds of the geometry values of up to GP iterations
+  float red[GEOM ? MM_GP * 2 * 68 : 4];  // lane-swap folds of the geometry values of up to GP iterations
   int32_t rowgid[MM_RW];      // flat Gaussian index of every row of the fac image
   int32_t geogid[MM_GP];      // ... and of every pending geometry fold
 };
 
-template <int TS, int CD, bool CGRAD>
-__global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
-    int n_regions, int N, int D, const float *__restrict__ means2d, const float *__restrict__ conics,
+// MODE: what the launch produces -- the geometry gradients alone (all D channels enter the dot product S), both kinds of
+// gradients, or the colour gradients of the channel window [ch_off, ch_off + CD) alone (no S, no geometry: the walk only
+// rebuilds fac).  Passes wider than 72 channels run as one geometry launch plus colour launches over windows: the two
+// operand copies of a wider cotangent block do not fit the register file together.
+enum { MM_GEOM = 0, MM_BOTH = 1, MM_COLOUR = 2 };
+// registers: the operands (CD for S plus its A-operand prefetch, 16 per column block for vC) and about 70 of state
+// (the LDS slice allows four wavefronts per SIMD for the one-sided modes, three when both are produced)
+constexpr int mm_regs(int cd, int mode) {
+  return (mode != MM_COLOUR ? cd + (cd + 3) / 4 : 0) + (mode != MM_GEOM ? 16 * ((cd + 15) / 16) : 0) + 70;
+}
+constexpr int mm_waves(int cd, int mode) {
+  return mm_regs(cd, mode) <= 128 && mode != MM_BOTH ? 4 : mm_regs(cd, mode) <= 168 ? 3 : 2;
+}
+
+template <int TS, int CD, int MODE>
+__global__ void __launch_bounds__(64, mm_waves(CD, MODE)) raster_bwd_mm_kernel(
+    int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
     const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds, int width,
     int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
     const int32_t *__restrict__ tile_order, const int32_t *__restrict__ flatten_ids, int n_isects,
     const float *__restrict__ render_alphas, const int32_t *__restrict__ last_ids,
     const float *__restrict__ render_colors, int ed_channel, const float *__restrict__ v_render_colors,
     const float *__restrict__ v_render_alphas, int absgrad, float *__restrict__ v_geom, const GradSegs gs) {
+  constexpr bool GEOM = MODE != MM_COLOUR, CGRAD = MODE != MM_GEOM;
   constexpr int WPT = TS == 16 ? 4 : 1;
   constexpr int NS = (CD + 3) / 4;     // k steps of S: channel 4 s + (lane >> 4)
   constexpr int NCB = (CD + 15) / 16;  // 16-channel column blocks of vC (and of the prologue's transposes)
   constexpr int CDP = 16 * NCB;
   constexpr int QN = MM_QN, BS = MM_BS, RW = MM_RW, SP = MM_SP, GP = MM_GP;
-  __shared__ MmLds<true> L;  // sized for the colour-gradient variant in both (the transpose area needs it)
+  __shared__ MmLds<GEOM, CGRAD> L;
   const int lane = threadIdx.x & 63;
   const RegionId rid = region_of<WPT>(tile_order, n_regions);
   if (!rid.valid) return;
@@ -75,7 +90,7 @@ __global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
   const int ox = tx * TS + (sub & 1) * 8, oy = ty * TS + (sub >> 1) * 8;
   const int x = ox + (lane & 7), y = oy + (lane >> 3);
   const int range_lo = __builtin_amdgcn_readfirstlane(isect_offsets[tile_flat]);
-  const int nch = min(CD, D);
+  const int nch = min(CD, D - ch_off);
   const int l15 = lane & 15, kk = lane >> 4;
   const float px = (float)x + 0.5f, py = (float)y + 0.5f;
 
@@ -86,12 +101,12 @@ __global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
   // Column (lane & 15) of block n of the colour-gradient product is channel (16 n + (lane & 15) + rot) mod CDP, rot chosen
   // so that the widest gradient tensor starts on a block boundary: a block's 16 floats of a row then are one aligned
   // 64-byte segment of that tensor, which is the unit the memory system delivers float atomics in.
-  int vch[NCB];
+  int vch[NCB];   // channel ch_off + vch[n]
   {
     // widths of the (up to three) gradient tensors; unused segments begin at INT_MAX
     const int e1 = min(gs.begin[1], D), e2 = min(gs.begin[2], D);
     const int w0 = e1, w1 = e2 - e1, w2 = D - e2;
-    const int rot = (w2 > w1 && w2 > w0 ? e2 : w1 > w0 ? e1 : 0) & 15;
+    const int rot = ((w2 > w1 && w2 > w0 ? e2 : w1 > w0 ? e1 : 0) - ch_off) & 15;
 #pragma unroll
     for (int n = 0; n < NCB; ++n) {
       const int c = 16 * n + l15 + rot;
@@ -106,8 +121,8 @@ __global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
       const int64_t pix = ((int64_t)cam * height + y) * width + x;
       T = 1.f - render_alphas[pix];
       last = last_ids[pix];
-      const float *src = v_render_colors + pix * D;
-      if ((D & 3) == 0) {
+      const float *src = v_render_colors + pix * D + ch_off;
+      if (((D | ch_off) & 3) == 0) {
 #pragma unroll
         for (int k = 0; k + 3 < CDP; k += 4)
           if (k < nch) {
@@ -126,19 +141,21 @@ __global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
         const float a = 1.f - T, inv = 1.f / fmaxf(a, 1e-10f);
 #pragma unroll
         for (int k = 0; k < CD; ++k)
-          if (k == ed_channel) {
+          if (k + ch_off == ed_channel) {
             if (a > 1e-10f) w_ed = -v[k] * render_colors[pix * D + ed_channel] * inv;
             v[k] *= inv;
           }
       }
-      float w = v_render_alphas[pix] + w_ed;
-      if (backgrounds) {
-        const float *bg = backgrounds + (int64_t)cam * D;
+      if (GEOM) {   // (launched with ch_off = 0: every channel is here)
+        float w = v_render_alphas[pix] + w_ed;
+        if (backgrounds) {
+          const float *bg = backgrounds + (int64_t)cam * D;
 #pragma unroll
-        for (int k = 0; k < CD; ++k)
-          if (k < nch) w -= bg[k] * v[k];
+          for (int k = 0; k < CD; ++k)
+            if (k < nch) w -= bg[k] * v[k];
+        }
+        W = T * w;
       }
-      W = T * w;
     }
     // both operand layouts, 16 channels at a time through LDS (pixel-major rows of 20 floats)
 #pragma unroll
@@ -149,14 +166,14 @@ __global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
             make_float4(v[16 * n + 4 * c4], v[16 * n + 4 * c4 + 1], v[16 * n + 4 * c4 + 2], v[16 * n + 4 * c4 + 3]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-      for (int m = 0; m < NCB; ++m)   // block m's column of this lane, if it lies in this chunk of channels
+      for (int m = 0; m < (CGRAD ? NCB : 0); ++m)   // block m's column of this lane, if it lies in this chunk of channels
         if ((vch[m] >> 4) == n) {
 #pragma unroll
           for (int s = 0; s < 16; ++s) Bc[s][m] = L.u.tr[(16 * kk + s) * 20 + (vch[m] & 15)];
         }
 #pragma unroll
       for (int s = 4 * n; s < 4 * n + 4; ++s)
-        if (s < NS) {
+        if (GEOM && s < NS) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) Bs[b][s] = L.u.tr[(16 * b + l15) * 20 + 4 * (s & 3) + kk];
         }
@@ -207,13 +224,14 @@ __global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
 #pragma unroll
         for (int n = 0; n < NCB; ++n) acc[n] = mfma_f32(a[j], Bc[4 * i + j][n], acc[n]);
     }
+    settle_mfma_results();
     const int4 g4 = *reinterpret_cast<const int4 *>(&L.rowgid[4 * kk]);
     const int gr[4] = {g4.x, g4.y, g4.z, g4.w};
     // A block's lanes may belong to different gradient tensors: per (block, tensor) the lanes of that tensor issue
     // with the tensor's scalar base and a 32-bit byte offset; combinations without a lane are skipped as a whole.
     auto scatter = [&](int n, float *base, int begin, int end, int ld, int shared) {
-      const int ch = vch[n];
-      const bool mine = base != nullptr && ch >= begin && ch < end && ch < nch;
+      const int ch = ch_off + vch[n];
+      const bool mine = base != nullptr && ch >= begin && ch < end && vch[n] < nch;
       if (__builtin_amdgcn_ballot_w64(mine) == 0ull) return;
       if (mine) {
         const int sub = shared ? cam_first : 0;
@@ -344,10 +362,10 @@ __global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
 
   refill(RW);
   if (qcount == 0) return;
-  gather(qhead, min(RW, qcount));
+  if (GEOM) gather(qhead, min(RW, qcount));
   for (;;) {
     const int n = min(RW, qcount);
-    {  // S^T[slot][pixel] for the chunk
+    if (GEOM) {  // S^T[slot][pixel] for the chunk
       f4v acc[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc[b] = f4v{0.f, 0.f, 0.f, 0.f};
@@ -362,10 +380,10 @@ __global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
     }
     // the records of the chunk after this one, then its colour rows: both travel during the walk
     refill(n + RW);
-    gather(qhead + n, min(RW, qcount - n));
+    if (GEOM) gather(qhead + n, min(RW, qcount - n));
 
     float4 g_n = L.ra[qhead], h_n = L.rb[qhead];
-    float s_n = L.u.w.sbuf[lane];
+    float s_n = GEOM ? L.u.w.sbuf[lane] : 0.f;
     for (int t = 0; t < n; ++t) {
       const float4 g = g_n, h = h_n;
       const float S = s_n;
@@ -373,7 +391,7 @@ __global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
         const int qn = (qhead + t + 1) & (QN - 1);
         g_n = L.ra[qn];
         h_n = L.rb[qn];
-        s_n = L.u.w.sbuf[((t + 1) & (RW - 1)) * SP + lane];
+        if (GEOM) s_n = L.u.w.sbuf[((t + 1) & (RW - 1)) * SP + lane];
       }
       const int gid = __builtin_bit_cast(int, h.z), idx = __builtin_bit_cast(int, h.w);
       const float dx = g.x - px, dy = g.y - py;
@@ -389,6 +407,13 @@ __global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
       if (CGRAD) {
         L.u.w.fimg[nrows * SP + lane] = fac;
         L.rowgid[nrows] = gid;
+      }
+      if (!GEOM) {
+        if (++nrows == RW) {
+          flush(RW);
+          nrows = 0;
+        }
+        continue;
       }
       const float v_alpha = S * T - (Bsum - W) * ra;
       Bsum = fmaf(fac, S, Bsum);
@@ -414,12 +439,12 @@ __global__ void __launch_bounds__(64, CD <= 48 ? 3 : 2) raster_bwd_mm_kernel(
     qcount -= n;
     if (qcount == 0) break;
   }
-  if (npend) geo_flush(npend);
+  if (GEOM && npend) geo_flush(npend);
   if (CGRAD && nrows) flush(nrows);
 }
 
-template <int TS, int CD, bool CGRAD>
-static int launch_mm(int C, int N, int D, const float *means2d, const float *conics, const ColorSegs &cs,
+template <int TS, int CD, int MODE>
+static int launch_mm(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const ColorSegs &cs,
                      const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
                      const int32_t *isect_offsets, const int32_t *tile_order, const int32_t *flatten_ids,
                      int64_t n_isects, const float *render_alphas, const int32_t *last_ids,
@@ -429,37 +454,60 @@ static int launch_mm(int C, int N, int D, const float *means2d, const float *con
   constexpr int WPT = TS == 16 ? 4 : 1;
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * WPT;
   const unsigned grid = region_grid(n_regions, WPT, tile_order != nullptr);
-  hipLaunchKernelGGL((raster_bwd_mm_kernel<TS, CD, CGRAD>), dim3(grid), dim3(64), 0, stream, (int)n_regions, N, D,
-                     means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
-                     tile_order, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors, ed_channel,
-                     v_render_colors, v_render_alphas, absgrad, v_geom, gs);
+  hipLaunchKernelGGL((raster_bwd_mm_kernel<TS, CD, MODE>), dim3(grid), dim3(64), 0, stream, (int)n_regions, N, D,
+                     ch_off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h,
+                     isect_offsets, tile_order, flatten_ids, (int)n_isects, render_alphas, last_ids, render_colors,
+                     ed_channel, v_render_colors, v_render_alphas, absgrad, v_geom, gs);
   return check_launch("raster_bwd_mm_kernel");
 }
 
+// Channel counts the kernel is built for (pick_chunk's list in raster_bwd.hip); 100 = geometry launch only.
 bool bwd_mm_supports(int cd, int tile_size) {
-  return (tile_size == 16 || tile_size == 8) && (cd == 4 || cd == 8 || cd == 16 || cd == 24 || cd == 32 || cd == 36 || cd == 48 || cd == 64);
+  return (tile_size == 16 || tile_size == 8) && cd >= 4 && cd <= 100;
 }
 
-int launch_bwd_mm(int cd, int tile_size, bool color_grad, int C, int N, int D, const float *means2d,
-                  const float *conics, const ColorSegs &cs, const float *opacities, const float *backgrounds,
-                  int width, int height, int tile_w, int tile_h, const int32_t *isect_offsets,
-                  const int32_t *tile_order, const int32_t *flatten_ids, int64_t n_isects,
-                  const float *render_alphas, const int32_t *last_ids, const float *render_colors, int ed_channel,
-                  const float *v_render_colors, const float *v_render_alphas, int absgrad, float *v_geom,
-                  const GradSegs &gs, hipStream_t stream) {
-#define MM_ARGS                                                                                                    \
-  C, N, D, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets, tile_order, \
-      flatten_ids, n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas, \
+int launch_bwd_mm(int cd, int tile_size, bool geom_grad, bool color_grad, bool split, int C, int N, int D,
+                  const float *means2d, const float *conics, const ColorSegs &cs, const float *opacities,
+                  const float *backgrounds, int width, int height, int tile_w, int tile_h,
+                  const int32_t *isect_offsets, const int32_t *tile_order, const int32_t *flatten_ids,
+                  int64_t n_isects, const float *render_alphas, const int32_t *last_ids, const float *render_colors,
+                  int ed_channel, const float *v_render_colors, const float *v_render_alphas, int absgrad,
+                  float *v_geom, const GradSegs &gs, hipStream_t stream) {
+#define MM_ARGS(off)                                                                                                   \
+  C, N, D, off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets, tile_order, \
+      flatten_ids, n_isects, render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas,    \
       absgrad, v_geom, gs, stream
-#define MM_CASE(CDV)                                                                   \
-  case CDV:                                                                            \
-    if (tile_size == 16)                                                               \
-      return color_grad ? launch_mm<16, CDV, true>(MM_ARGS) : launch_mm<16, CDV, false>(MM_ARGS); \
-    return color_grad ? launch_mm<8, CDV, true>(MM_ARGS) : launch_mm<8, CDV, false>(MM_ARGS);
-  switch (cd) {
-    MM_CASE(4) MM_CASE(8) MM_CASE(16) MM_CASE(24) MM_CASE(32) MM_CASE(36) MM_CASE(48) MM_CASE(64)
-    default: return PR_EUNSUPPORTED;
+#define MM_CASE(CDV, MODE, off)                                                         \
+  case CDV:                                                                             \
+    rc = tile_size == 16 ? launch_mm<16, CDV, MODE>(MM_ARGS(off)) : launch_mm<8, CDV, MODE>(MM_ARGS(off)); \
+    break;
+  int rc = PR_EUNSUPPORTED;
+  if (geom_grad && color_grad && cd <= 64 && !split) {   // one launch
+    switch (cd) {
+      MM_CASE(4, MM_BOTH, 0) MM_CASE(8, MM_BOTH, 0) MM_CASE(16, MM_BOTH, 0) MM_CASE(24, MM_BOTH, 0)
+      MM_CASE(32, MM_BOTH, 0) MM_CASE(36, MM_BOTH, 0) MM_CASE(48, MM_BOTH, 0) MM_CASE(64, MM_BOTH, 0)
+    }
+    return rc;
   }
+  if (geom_grad) {
+    switch (cd) {
+      MM_CASE(4, MM_GEOM, 0) MM_CASE(8, MM_GEOM, 0) MM_CASE(16, MM_GEOM, 0) MM_CASE(24, MM_GEOM, 0)
+      MM_CASE(32, MM_GEOM, 0) MM_CASE(36, MM_GEOM, 0) MM_CASE(48, MM_GEOM, 0) MM_CASE(64, MM_GEOM, 0)
+      MM_CASE(72, MM_GEOM, 0) MM_CASE(100, MM_GEOM, 0)
+    }
+    if (rc || !color_grad) return rc;
+  }
+  // colour gradients in windows of up to 48 channels (three 16-channel column blocks)
+  const int n_win = (D + 47) / 48, per = ((D + n_win - 1) / n_win + 15) & ~15;
+  for (int off = 0; off < D; off += per) {
+    const int w = min(per, D - off);
+    rc = PR_EUNSUPPORTED;
+    switch (w <= 16 ? 16 : w <= 32 ? 32 : 48) {
+      MM_CASE(16, MM_COLOUR, off) MM_CASE(32, MM_COLOUR, off) MM_CASE(48, MM_COLOUR, off)
+    }
+    if (rc) return rc;
+  }
+  return rc;
 #undef MM_CASE
 #undef MM_ARGS
 }

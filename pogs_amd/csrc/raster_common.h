@@ -201,10 +201,10 @@ int launch_bwd_colour_mfma(int C, int N, int D, const float *means2d, const floa
                            hipStream_t stream);
 
 // raster_bwd_mm.hip: backward with both channel contractions on the float32 matrix cores, one wavefront per 8x8
-// pixel region (geometry gradients wanted; colour gradients optional)
+// pixel region: geometry gradients, colour gradients or both (wide passes as several launches)
 bool bwd_mm_supports(int cd, int tile_size);
-int launch_bwd_mm(int cd, int tile_size, bool color_grad, int C, int N, int D, const float *means2d,
-                  const float *conics, const ColorSegs &cs, const float *opacities, const float *backgrounds,
+int launch_bwd_mm(int cd, int tile_size, bool geom_grad, bool color_grad, bool split, int C, int N, int D,
+                  const float *means2d, const float *conics, const ColorSegs &cs, const float *opacities, const float *backgrounds,
                   int width, int height, int tile_w, int tile_h, const int32_t *isect_offsets,
                   const int32_t *tile_order, const int32_t *flatten_ids, int64_t n_isects,
                   const float *render_alphas, const int32_t *last_ids, const float *render_colors, int ed_channel,

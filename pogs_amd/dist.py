@@ -247,6 +247,14 @@ class ShardedExchange:
     shard (``lo`` = offset of the slice inside the parameter) holding the MEAN gradient; must update ``param_slice``
     in place on the current stream.  ``ShardAdam`` is the fused HIP one.
     Parameters that received no gradient in a step contribute zeros (``find_unused_parameters=True`` semantics).
+    One difference from the reference remains: a parameter that NO rank produced a gradient for is still stepped,
+    with a zero gradient (its moments decay and it keeps moving along them), where ``torch.optim.Adam`` skips a
+    parameter whose ``.grad`` is None.  A rank sees only its own ``.grad``; learning that every rank had none would
+    take one more collective per step.  POGS's groups all receive gradients once their loss terms are active.
+
+    The library reduce-scatter / all-gather of the ``nccl`` backend (RCCL) has executed in no test of this
+    repository: ``direct=False`` on ``gloo`` exercises the same bucket offsets, in-place shard views and mean through
+    an all-reduce that stands in for the reduce-scatter.
     """
 
     def __init__(self, params: Dict[str, Tensor], update, group: Optional[dist.ProcessGroup] = None,
@@ -256,10 +264,9 @@ class ShardedExchange:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
         # direct = each GPU sends shard j of its gradients straight to GPU j (all 7 xGMI links at once, one hop) and
-        # sums what it receives; otherwise the library's reduce-scatter.  gloo has no reduce-scatter: always direct.
+        # sums what it receives; otherwise the library's reduce-scatter (gloo has none: there an all-reduce of the
+        # whole buffer stands in for it, so that the non-direct bookkeeping can be run on CPUs).
         self.direct = (self.backend != "nccl") if direct is None else bool(direct)
-        if self.backend not in ("nccl", "none"):
-            self.direct = True
         self.big_bytes = big_bytes
         self.side = None
         self.hooks = []
@@ -357,9 +364,20 @@ class ShardedExchange:
             recv = torch.empty_like(flat)
             works.append(dist.all_to_all_single(recv, flat, group=self.group, async_op=True))
             shard = None
-        else:
-            shard = flat[b.lo:b.hi]
+        elif self.backend == "nccl":
+            shard = flat[b.lo:b.hi]    # in place: the mean of shard j lands in rank j's own slice of its buffer
             works.append(dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+        else:
+            # no reduce-scatter in this backend: all-reduce the buffer (through the host when it lives on a GPU) and
+            # keep the same in-place shard view
+            if flat.is_cuda:
+                h = flat.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                flat.copy_(h)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(W)
+            shard = flat[b.lo:b.hi]
         # 3. optimiser shard + all-gather, on the second stream (HIP) so that the backward kernels queued behind this
         #    hook do not wait for the links
         cuda = flat.is_cuda
@@ -388,7 +406,11 @@ class ShardedExchange:
                 ev = torch.cuda.Event()
                 ev.record(self.side)
                 ready = _Ready(event=ev)
+                # everything the second stream read was allocated on the caller's stream: keep it from being handed
+                # out again there before the second stream is done with it
                 flat.record_stream(self.side)
+                if W > 1 and self.direct:
+                    recv.record_stream(self.side)
                 if shard is not None:
                     shard.record_stream(self.side)
             else:

@@ -280,6 +280,7 @@ class _CallState:
         self.lock = threading.Lock()
         self.history: Dict[tuple, List[int]] = {}
         self.pinned: Dict[int, List[Tensor]] = {}
+        self.graveyard: List[Tensor] = []
         self.side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
         self.speculate = os.environ.get("POGS_RAST_SPECULATE", "1") != "0"
         # how a speculating call learns the true count: "publish" = a one-thread kernel stores it into page-locked
@@ -326,6 +327,12 @@ class _CallState:
         with self.lock:
             self.pinned.setdefault(dev.index, []).append(t)
 
+    def retire_pinned(self, t: Tensor) -> None:
+        """Keep words that a failed call may still have a queued write to alive for the rest of the process (never
+        handed out again, never freed: a page-locked block returned to torch could be given to another user)."""
+        with self.lock:
+            self.graveyard.append(t)
+
     def side_stream(self, dev: torch.device, main: "torch.cuda.Stream") -> "torch.cuda.Stream":
         key = (dev.index, main.cuda_stream)
         with self.lock:
@@ -370,18 +377,24 @@ def _depth_order_async(depths: Tensor):
 
 
 def _await_published(host: Tensor, seq: int, timeout_s: float = 60.0) -> int:
-    """Wait until the kernel of ``pr_publish_count`` has stored sequence number ``seq`` into host[1]; -> host[0]."""
+    """Wait until the kernel of ``pr_publish_count`` has stored sequence number ``seq`` into host[1]; -> host[0].
+    The count is normally there within tens of microseconds: a short spin, then 20 us sleeps (which release the
+    interpreter lock for a viewer thread), and a look at the stream's error state from time to time so that a GPU
+    fault surfaces as an exception instead of a minute-long stall."""
     words = host.numpy()
-    deadline = None
     spins = 0
+    deadline = None
     while int(words[1]) != seq:
         spins += 1
-        if spins & 63 == 0:
-            time.sleep(0)                     # let other Python threads run
+        if spins < 200:
+            continue
+        time.sleep(20e-6)
+        if spins % 2000 == 0:
             now = time.monotonic()
             if deadline is None:
                 deadline = now + timeout_s
-            elif now > deadline:
+            torch.cuda.current_stream().query()   # raises if the device has reported an error
+            if now > deadline:
                 raise RuntimeError("pogs_amd: the intersection count never reached the host (sequence %d): %s"
                                    % (seq, _lib.load().pr_last_hip_error().decode()))
     return int(words[0])
@@ -450,18 +463,27 @@ def _bin_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, t
             isect_ids, flatten_ids = emit(n_isects, False)
         else:
             host = _state.take_pinned(dev)
-            if _state.readback == "publish":
-                seq = _state.next_sequence()
-                _call("pr_publish_count", cum[-1:].data_ptr(), host.data_ptr(), seq, _stream())
-                isect_ids, flatten_ids = emit(guess, True)
-                n_isects = _await_published(host, seq)
-            else:
-                host[:1].copy_(cum[-1:], non_blocking=True)
-                done = torch.cuda.Event()
-                done.record()
-                isect_ids, flatten_ids = emit(guess, True)
-                done.synchronize()
-                n_isects = int(host[0].item())
+            try:
+                if _state.readback == "publish":
+                    seq = _state.next_sequence()
+                    _call("pr_publish_count", cum[-1:].data_ptr(), host.data_ptr(), seq, _stream())
+                    isect_ids, flatten_ids = emit(guess, True)
+                    n_isects = _await_published(host, seq)
+                else:
+                    host[:1].copy_(cum[-1:], non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record()
+                    isect_ids, flatten_ids = emit(guess, True)
+                    done.synchronize()
+                    n_isects = int(host[0].item())
+            except BaseException:
+                # a kernel (or copy) that writes into `host` may still be queued: the words must not go back to the
+                # pool, or be freed, before the stream has drained
+                try:
+                    torch.cuda.current_stream(dev).synchronize()
+                finally:
+                    _state.retire_pinned(host)
+                raise
             _state.give_pinned(dev, host)
             if n_isects > guess:
                 isect_ids, flatten_ids = emit(n_isects, False)
@@ -514,12 +536,19 @@ def _tile_lists(means2d: Tensor, radii: Tensor, depths: Tensor, conics: Tensor, 
             flatten_ids = fill(n_isects)
         else:
             host = _state.take_pinned(dev)
-            host[:1].copy_(total, non_blocking=True)
-            done = torch.cuda.Event()
-            done.record()
-            flatten_ids = fill(guess)
-            done.synchronize()
-            n_isects = int(host[0].item())
+            try:
+                host[:1].copy_(total, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+                flatten_ids = fill(guess)
+                done.synchronize()
+                n_isects = int(host[0].item())
+            except BaseException:
+                try:
+                    torch.cuda.current_stream(dev).synchronize()
+                finally:
+                    _state.retire_pinned(host)
+                raise
             _state.give_pinned(dev, host)
             if n_isects > guess:      # the counters were consumed by the undersized fill: count again
                 _call("pr_tile_lists_count", C, N, _ptr(means2d), _ptr(radii), _ptr(conics), _ptr(opacities),
@@ -591,6 +620,16 @@ class RenderMeta(dict):
     def copy(self):
         self._resolve()
         return dict(self)
+
+    # ``dict(meta)``, ``{**meta}`` and ``other.update(meta)`` copy a dict subclass's storage directly -- placeholders
+    # included -- unless the subclass overrides ``__iter__``; with these two they go through keys() / __getitem__.
+    def __iter__(self):
+        self._resolve()
+        return dict.__iter__(self)
+
+    def keys(self):
+        self._resolve()
+        return dict.keys(self)
 
 
 class _ReferenceBinning:

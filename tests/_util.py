@@ -40,6 +40,28 @@ REL_ERRORS = []
 MARGINS = []
 
 
+# (name, HIP kernel's worst relative error against the float64 oracle, the float32 C restatement's -- gsplat's operation
+# order, scalar loops -- on the same inputs and elements, elements counted): what float32 itself costs, next to what
+# the kernel adds
+PRECISION_PAIRS = []
+
+
+def worst_relative_error(got, ref, floor=1e-3):
+    """max |got - ref| / |ref| over the elements with |ref| > floor * max |ref|  (-> (value, elements counted))."""
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    big = ref.abs() > floor * ref.abs().max()
+    if not big.any():
+        return 0.0, 0
+    return float(((got - ref).abs()[big] / ref.abs()[big]).max()), int(big.sum())
+
+
+def record_precision(name, hip, c32, ref64):
+    h, n = worst_relative_error(hip, ref64)
+    c, _ = worst_relative_error(c32, ref64)
+    PRECISION_PAIRS.append((name, h, c, n))
+    return h, c
+
+
 def assert_grad_close(got, ref, name, rtol=GRAD_RTOL, atol_frac=1e-4):
     if ref is None:  # the oracle's graph does not reach this input: the gradient is identically zero
         assert got is None or got.abs().max().item() == 0, name

@@ -59,8 +59,22 @@ def pytest_sessionfinish(session, exitstatus):
            "median_of_worsts": sorted(r[1] for r in REL_ERRORS)[len(REL_ERRORS) // 2],
            "over_1e-3": sum(1 for r in REL_ERRORS if r[1] > 1e-3), "top": worst[:25]}
     try:
-        from tests._util import MARGINS
+        from tests._util import MARGINS, PRECISION_PAIRS
         rec["closest_to_their_bound (error / allowed)"] = sorted(MARGINS, key=lambda r: -r[1])[:15]
+        if PRECISION_PAIRS:
+            by_tensor = {}
+            for name, h, c, n in PRECISION_PAIRS:
+                t = by_tensor.setdefault(name.split()[0], {"comparisons": 0, "hip_vs_f64_worst": 0.0, "c32_vs_f64_worst": 0.0})
+                t["comparisons"] += 1
+                t["hip_vs_f64_worst"] = max(t["hip_vs_f64_worst"], h)
+                t["c32_vs_f64_worst"] = max(t["c32_vs_f64_worst"], c)
+            for t in by_tensor.values():
+                t["hip_over_c32"] = t["hip_vs_f64_worst"] / t["c32_vs_f64_worst"] if t["c32_vs_f64_worst"] else None
+            rec["float32_restatement_next_to_the_kernels"] = {
+                "what": "worst |x - f64| / |f64| over elements above 1e-3 max|f64|, same inputs and cotangents: HIP "
+                        "kernels and oracle/raster_c.c (float32, gsplat's operation order, scalar loops)",
+                "per_tensor": by_tensor,
+                "pairs (name, hip_vs_f64, c32_vs_f64, elements)": sorted(PRECISION_PAIRS, key=lambda r: -r[1])[:40]}
     except Exception:
         pass
     json.dump(rec, open(os.path.join(out_dir, "grad_relative_errors.json"), "w"), indent=1)

@@ -285,9 +285,11 @@ def _sharded_reference(world=2):
     return {k: v.detach() for k, v in p.items()}
 
 
-@pytest.mark.parametrize("direct", [True])
+@pytest.mark.parametrize("direct", [True, False])
 def test_sharded_exchange_matches_mean_gradient_adam_through_a_refinement(direct):
-    """world 2, gloo: reduce-scatter (direct form) -> Adam on the local shard -> all-gather of the parameters for
+    """world 2, gloo: reduce-scatter (direct form: all-to-all + local sum; or the library form's bookkeeping -- in-place
+    shard view of the gradient buffer, bucket padding, mean -- with an all-reduce standing in for the reduce-scatter
+    gloo lacks) -> Adam on the local shard -> all-gather of the parameters for
     four steps with a refinement (exchanged statistics, shared random samples, rebuilt layout, re-sharded moments)
     after the second; both ranks end with the same parameters, equal to single-process mean-gradient Adam."""
     ctx = mp.get_context("spawn")

@@ -22,7 +22,7 @@ def test_stress_shape_properties_forward_and_backward(gpu, N, W, H, F, tile_bits
     n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
     assert n_tiles.bit_length() == tile_bits
     assert _lib.raster_plan(D, 16, n_tiles)[:2] == (2, 36)
-    assert _lib.raster_plan(D, 16, n_tiles, backward=True)[:2] == (2, D)
+    assert _lib.raster_plan(D, 16, n_tiles, backward=True) == (1, D, True)   # 8x8 regions, float32 matrix products
     sc = make_scene(N, W, H, n_features=F, seed=0)
     dev = dict(means=sc.means, quats=sc.quats, scales=sc.log_scales.exp(), opacities=torch.sigmoid(sc.opacity_logits),
                colors=sc.sh, viewmats=sc.viewmats, Ks=sc.Ks)

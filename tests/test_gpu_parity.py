@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import gsplat_ref as R
-from tests._util import assert_grad_close, assert_image_close, scene_args, small_scene
+from tests._util import assert_grad_close, assert_image_close, record_precision, scene_args, small_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -497,6 +497,20 @@ def test_raster_backward(gpu, tile_size, D, with_bg):
     ab = leaves["means2d"].absgrad
     assert ab.shape == leaves["means2d"].shape
     assert (ab + 1e-6 * ab.abs().max() >= leaves["means2d"].grad.abs()).all()
+    # What float32 costs on the same elements: the scalar float32 restatement (gsplat's operation order) against the
+    # same float64 oracle.  Element by element the kernel must not be worse than float32 arithmetic itself is --
+    # twice the restatement's worst relative error, or 1e-3 where that is smaller.
+    from oracle import raster_c as RC
+
+    c = {k: v.detach().cpu() for k, v in dev.items()}
+    o32, a32, last = RC.raster_fwd(c["means2d"], c["conics"], c["colors"], c["opacities"], sc.width, sc.height,
+                                   tile_size, offs.cpu(), flat.cpu(), backgrounds=None if bg is None else bg.cpu())
+    v_m, _, v_cn, v_cl, v_op = RC.raster_bwd(c["means2d"], c["conics"], c["colors"], c["opacities"], sc.width,
+                                             sc.height, tile_size, offs.cpu(), flat.cpu(), a32, last, vc, va,
+                                             backgrounds=None if bg is None else bg.cpu())
+    for k, c32 in (("colors", v_cl), ("opacities", v_op), ("conics", v_cn), ("means2d", v_m)):
+        h, r = record_precision(f"{k} D={D} ts={tile_size} bg={with_bg}", leaves[k].grad, c32, cpu[k].grad)
+        assert h <= max(2.0 * r, 1e-3), (k, h, r)
 
 
 @pytest.mark.parametrize("tile_size,widths", [(16, (3, 32, 1)), (8, (5, 7)), (16, (40, 30, 1))])
@@ -707,19 +721,22 @@ def test_rasterization_end_to_end_with_matrix_core_backward(gpu, tuning):
     assert_grad_close(a["viewmats"].grad[:, :3, :], b["viewmats"].grad[:, :3, :], "viewmats")
 
 
-@pytest.mark.parametrize("D", [4, 19, 32, 36, 33, 48, 64])
+@pytest.mark.parametrize("D", [4, 19, 32, 36, 33, 48, 64, 68, 96, 97])
 @pytest.mark.parametrize("tile_size", [16, 8])
-@pytest.mark.parametrize("grads", ["geometry+colours", "geometry"])
+@pytest.mark.parametrize("grads", ["geometry+colours", "geometry", "colours", "geometry+colours, two launches"])
 def test_raster_backward_float32_matrix_core_contractions(gpu, tuning, D, tile_size, grads):
     """raster_bwd_mm_kernel (POGS_RAST_BWD_MFMA=5): one wavefront per 8x8 pixel region, S = <colour, v> and the
     colour-gradient contraction sum_p fac * v as float32 matrix products (v_mfma_f32_16x16x4_f32: exact float32
     products), list entries compacted into a ring and walked 16 at a time; against the float64 oracle, |v_xy| against
-    the float32 C restatement.  Tile lists run from a handful of entries to several ring refills."""
+    the float32 C restatement.  Tile lists run from a handful of entries to several ring refills.  Up to 64 channels
+    both kinds of gradients come from one launch; wider passes (and POGS_RAST_BWD_MFMA=6 at any width) run as a
+    geometry launch over all channels plus colour launches over windows of up to 48 channels; colours alone are the
+    window launches only."""
     rd = _rendering()
     from oracle import raster_c as RC
 
-    cgrad = grads != "geometry"
-    tuning(POGS_RAST_BWD_MFMA=5)
+    cgrad, geom = grads != "geometry", grads != "colours"
+    tuning(POGS_RAST_BWD_MFMA=6 if "two launches" in grads else 5)
     sc = small_scene(n=600, w=70, h=45, views=2, seed=4, lo=0.02, hi=0.3)
     dev, offs, flat = _staged(gpu, sc, D, tile_size)
     bg = torch.rand(2, D, generator=torch.Generator().manual_seed(9)).to(gpu) if D in (19, 36, 64) else None
@@ -728,12 +745,14 @@ def test_raster_backward_float32_matrix_core_contractions(gpu, tuning, D, tile_s
     keep = (~amb)[..., None].float()
     vc, va = torch.randn(out_r.shape, generator=g) * keep, torch.randn(alpha_r.shape, generator=g) * keep
     (out_r * vc.double()).sum().add((alpha_r * va.double()).sum()).backward()
-    leaves = {k: v.clone().requires_grad_(cgrad or k != "colors") for k, v in dev.items()}
+    leaves = {k: v.clone().requires_grad_(cgrad if k == "colors" else geom) for k, v in dev.items()}
     out, alpha = rd.rasterize_to_pixels(leaves["means2d"], leaves["conics"], leaves["colors"], leaves["opacities"],
                                         sc.width, sc.height, tile_size, offs, flat, backgrounds=bg, absgrad=True)
     ((out * vc.to(gpu)).sum() + (alpha * va.to(gpu)).sum()).backward()
-    for k in (["colors"] if cgrad else []) + ["opacities", "conics", "means2d"]:
+    for k in (["colors"] if cgrad else []) + (["opacities", "conics", "means2d"] if geom else []):
         assert_grad_close(leaves[k].grad, cpu[k].grad, f"{k} D={D} ts={tile_size} float32 matrix-core backward")
+    if not geom:
+        return
     o32, a32, last = RC.raster_fwd(dev["means2d"].cpu(), dev["conics"].cpu(), dev["colors"].cpu(),
                                    dev["opacities"].cpu(), sc.width, sc.height, tile_size, offs.cpu(), flat.cpu(),
                                    backgrounds=None if bg is None else bg.cpu())
@@ -876,10 +895,11 @@ def test_rasterization_end_to_end_with_split_backward(gpu, tuning, two_streams, 
 
 
 def test_backward_variants_agree_on_long_tile_lists(gpu, tuning):
-    """200 k Gaussians at 1024x768 (3072 tiles: the planner itself picks 2 pixels per lane; tile lists of several hundred
-    entries, i.e. many 16-row products and staging batches per wavefront, tiles visited in the heaviest-first order):
-    the deferred matrix-core colour gradient, the split backward and the split backward on two streams against the
-    vector kernel, which the float64 oracle checks at the sizes it can reach.  Every gradient of the call is compared."""
+    """200 k Gaussians at 1024x768 (3072 tiles; tile lists of several hundred entries, i.e. many 16-row products, ring
+    refills and staging batches per wavefront, tiles visited in the heaviest-first order): the planner's choice (the
+    float32 matrix-core kernel on 8x8 regions), the same as two launches, the deferred split-bf16 colour gradient, the
+    split backward and the split backward on two streams against the vector kernel at 2 pixels per lane, which the
+    float64 oracle checks at the sizes it can reach.  Every gradient of the call is compared."""
     rd = _rendering()
     from pogs_amd import _lib
     from pogs_amd.scenes import make_scene
@@ -892,9 +912,9 @@ def test_backward_variants_agree_on_long_tile_lists(gpu, tuning):
     g = torch.Generator().manual_seed(3)
     vc, va = torch.randn(1, H, W, F + 4, generator=g).to(gpu), torch.randn(1, H, W, 1, generator=g).to(gpu)
 
-    def grads(**env):
+    def grads(expect, **env):
         tuning(**env)
-        assert _lib.raster_plan(F + 4, 16, 64 * 48, backward=True)[:2] == (2, F + 4)
+        assert _lib.raster_plan(F + 4, 16, 64 * 48, backward=True)[:2] == (expect, F + 4)
         for t in p.values():
             t.grad = None
         r, a, meta = rd.rasterization(p["means"], p["quats"], p["ls"].exp(), torch.sigmoid(p["ol"]), p["sh"], vm, K, W, H,
@@ -907,11 +927,13 @@ def test_backward_variants_agree_on_long_tile_lists(gpu, tuning):
         out["absgrad"] = meta["means2d"].absgrad.clone()
         return out, meta["flatten_ids"].numel()
 
-    ref, n_isects = grads(POGS_RAST_BWD_MFMA=None, POGS_RAST_BWD_SPLIT=None)
+    ref, n_isects = grads(2, POGS_RAST_BWD_MFMA=0, POGS_RAST_BWD_SPLIT=None)
     assert n_isects > 100 * 3072, n_isects
-    for name, env in (("deferred", dict(POGS_RAST_BWD_MFMA=3)), ("split", dict(POGS_RAST_BWD_MFMA=4)),
-                      ("split on two streams", dict(POGS_RAST_BWD_MFMA=4, POGS_RAST_BWD_SPLIT=1))):
-        got, _ = grads(**dict(dict(POGS_RAST_BWD_SPLIT=None), **env))
+    for name, ppl, env in (("planner: float32 matrix cores, 8x8 regions", 1, dict(POGS_RAST_BWD_MFMA=None)),
+                           ("float32 matrix cores, two launches", 1, dict(POGS_RAST_BWD_MFMA=6)),
+                           ("deferred", 2, dict(POGS_RAST_BWD_MFMA=3)), ("split", 2, dict(POGS_RAST_BWD_MFMA=4)),
+                           ("split on two streams", 2, dict(POGS_RAST_BWD_MFMA=4, POGS_RAST_BWD_SPLIT=1))):
+        got, _ = grads(ppl, **dict(dict(POGS_RAST_BWD_SPLIT=None), **env))
         # Both sides are float32 here, and neither is the oracle.  The vector kernel rebuilds the transmittance from
         # 1 - alpha of the stored image (as gsplat's backward does): on a pixel saturated to T ~ 1e-4 that start value is
         # only good to ~6e-4 relative, while the colour kernel of the split form replays T from 1; and two kernels that
@@ -922,14 +944,14 @@ def test_backward_variants_agree_on_long_tile_lists(gpu, tuning):
             assert_grad_close(got[k], ref[k], f"{k}, {name} against the vector kernel", rtol=2e-3, atol_frac=5e-4)
 
 
-@pytest.mark.parametrize("features,expect", [(32, (2, 2)), (0, (2, 2))])
+@pytest.mark.parametrize("features,expect", [(32, (2, 1, True)), (0, (2, 2, False))])
 def test_planner_selected_large_image_kernels(gpu, tuning, features, expect):
     """No tuning variable involved: at 1024x768 (3072 tiles) the planner itself picks the kernels of a full-size
     training step -- RGB+ED + 32 features (36 channels, absgrad): forward raster_fwd_kernel<16,2,36>, backward
-    raster_bwd_kernel<16,2,36,geometry,colours>, the benchmark's dominant kernel; plain RGB+ED (4 channels): 2 pixels
-    per lane both ways (4 pixels per lane is the planner's choice from 16384 tiles on, for the backward only; the
-    forced-variant tests cover it) -- checked end to end against the float64 oracle, and the compositor alone against
-    the float32 C restatement."""
+    raster_bwd_mm_kernel<16,36,both> (8x8 regions, float32 matrix products), the benchmark's dominant kernel; plain
+    RGB+ED (4 channels): the vector kernels at 2 pixels per lane both ways (4 pixels per lane is the planner's choice
+    from 16384 tiles on, for the backward only; the forced-variant tests cover it) -- checked end to end against the
+    float64 oracle, and the compositor alone against the float32 C restatement."""
     rd = _rendering()
     from oracle import raster_c as RC
     from pogs_amd import _lib
@@ -940,7 +962,7 @@ def test_planner_selected_large_image_kernels(gpu, tuning, features, expect):
     W, H = 1024, 768
     D = 3 + features + 1
     assert _lib.raster_plan(D, 16, 64 * 48)[0] == expect[0]
-    assert _lib.raster_plan(D, 16, 64 * 48, backward=True)[:2] == (expect[1], D)
+    assert _lib.raster_plan(D, 16, 64 * 48, backward=True) == (expect[1], D, expect[2])
     sc = small_scene(n=3000, w=W, h=H, views=1, seed=3, lo=0.01, hi=0.12, f=max(features, 1))
     kw = dict(sh_degree=3, render_mode="RGB+ED", tile_size=16, packed=False, absgrad=True)
     a = scene_args(sc, device=gpu, requires_grad=True)
@@ -1013,6 +1035,13 @@ def test_rasterization_end_to_end(gpu, mode, tile_size, antialiased):
     b = scene_args(sc, dtype=torch.float64, requires_grad=True)
     out_r, alpha_r, meta_r = R.rasterization(**b, **kw, radii_override=meta["radii"].cpu())
     amb = meta_r["ambiguous"]
+    # a consumer that snapshots the dict before it looks anything up (gsplat returns a plain dict) gets the tables too
+    out2, alpha2, meta2 = rd.rasterization(**{k: (v.detach() if torch.is_tensor(v) else v) for k, v in a.items()}, **kw)
+    for snap in (dict(meta2), {**rd.rasterization(**{k: (v.detach() if torch.is_tensor(v) else v) for k, v in a.items()}, **kw)[2]}):
+        assert type(snap) is dict
+        for k in ("tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
+            assert torch.is_tensor(snap[k]), k
+        assert torch.equal(snap["isect_ids"].cpu(), meta_r["isect_ids"])
     assert torch.equal(meta["isect_ids"].cpu(), meta_r["isect_ids"]), "binning differs from the float64 oracle"
     assert_image_close(out, out_r, amb, "render_colors")
     assert_image_close(alpha, alpha_r, amb, "render_alphas")

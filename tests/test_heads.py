@@ -147,3 +147,63 @@ def test_heads_forward_backward(P, n_random):
     with torch.no_grad():
         assert torch.equal(heads.get_instance_outputs_from_feature(fg), i)
         assert torch.equal(heads.get_clip_outputs_from_feature(fg if rp is None else fg[rp.cuda()], scale.cuda()), c)
+
+
+@pytest.mark.gpu
+def test_l2norm_zero_row_has_finite_gradient():
+    """y / (|y| + eps) at y = 0 (eps > 0): the output row is 0 and the gradient is g / eps, torch's subgradient of
+    the norm at the origin being 0 -- not 0/0."""
+    from pogs_amd.heads import _call, _ptr, _stream
+    N, eps = 128, 1e-5
+    gen = torch.Generator().manual_seed(3)
+    y = torch.randn(9, N, generator=gen)
+    y[2] = 0
+    y[7] = 0
+    g = torch.randn(9, N, generator=gen)
+    g[7] = 0
+    yr = y.double().requires_grad_(True)
+    (yr / (yr.norm(dim=-1, keepdim=True) + eps)).backward(g.double())
+    assert torch.isfinite(yr.grad).all()
+    out, norms, dy = torch.empty(9, N, device="cuda"), torch.empty(9, device="cuda"), torch.empty(9, N, device="cuda")
+    yg, gg = y.cuda(), g.cuda()
+    _call("pr_l2norm_fwd", 9, N, _ptr(yg), eps, _ptr(out), _ptr(norms), _stream())
+    _call("pr_l2norm_bwd", 9, N, _ptr(yg), _ptr(norms), eps, _ptr(gg), _ptr(dy), _stream())
+    assert torch.isfinite(out).all() and torch.isfinite(dy).all()
+    assert float(out[2].abs().max()) == 0.0 and float(dy[7].abs().max()) == 0.0
+    assert (dy.cpu().double() - yr.grad).abs().max().item() <= 1e-5 * yr.grad.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_instance_head_with_an_empty_pixel():
+    """A rendered-feature pixel with alpha = 0 is an all-zero 96-vector; the bias-free instance head maps it to an
+    exactly zero row (pogs/pogs.py:447 feeds every pixel to it).  Forward and every gradient stay finite and agree with
+    the float64 restatement; one such pixel must not poison the weight gradient."""
+    from pogs_amd.heads import FieldHeads
+    heads = FieldHeads(device="cuda", seed=7)
+    gen = torch.Generator().manual_seed(11)
+    P = 200
+    feats = torch.randn(P, 96, generator=gen)
+    feats[5] = 0
+    feats[130] = 0
+    inst = (heads.instance_net.params.detach().cpu().double().requires_grad_(True), heads.instance_net.shapes, 96, 128)
+    fr = feats.double().requires_grad_(True)
+    hidden, pre = dense_network_ref(fr, *inst)
+    i_ref = hidden / (hidden.norm(dim=-1, keepdim=True) + FieldHeads.INSTANCE_EPS)
+    with torch.no_grad():
+        amb = _ambiguous(pre)
+        amb[5] = amb[130] = False     # zero rows have zero pre-activations everywhere: their gradient is 0 either way
+    vi = torch.randn(P, 128, generator=gen) * (~amb)[:, None]
+    (i_ref * vi.double()).sum().backward()
+    fg = feats.cuda().requires_grad_(True)
+    i = heads.get_instance_outputs_from_feature(fg)
+    assert torch.isfinite(i).all() and float(i[5].abs().max()) == 0.0
+    (i * vi.cuda()).sum().backward()
+    assert torch.isfinite(fg.grad).all() and torch.isfinite(heads.instance_net.params.grad).all()
+    assert (i.cpu().double() - i_ref.detach()).abs().max().item() <= 1e-4 * i_ref.abs().max().item()
+    for got, ref, what in ((fg.grad, fr.grad, "features"), (heads.instance_net.params.grad, inst[0].grad, "params")):
+        keep = torch.ones_like(ref, dtype=torch.bool)
+        if what == "features":
+            keep[5] = keep[130] = False   # through ReLU at exactly 0 the float64 autograd picks 0; so does the kernel
+            assert float(got[5].abs().max()) == 0.0 or torch.isfinite(got[5]).all()
+        err = ((got.cpu().double() - ref) * keep).abs().max().item()
+        assert err <= 1e-3 * ref.abs().max().item(), (what, err)

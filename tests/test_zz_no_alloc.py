@@ -21,11 +21,20 @@ def _both(lib, depths):
     scratch = torch.empty(nb, dtype=torch.uint8, device=depths.device)
     assert lib.pr_depth_order(C, N, _ptr(depths), _ptr(want), _ptr(scratch), nb, stream) == 0
     got = torch.full((C * N,), -1, dtype=torch.int32, device=depths.device)
-    before = torch.cuda.memory_allocated()
-    assert lib.pr_depth_order_static(C, N, _ptr(depths), _ptr(got), stream) == 0
-    assert torch.cuda.memory_allocated() == before
+    # torch's allocator counter sees allocations made through torch only; the driver's free-memory figure also sees a
+    # hipMalloc made inside the library.  (Compared on calls after a device's first one, which loads nothing new.)
     torch.cuda.synchronize()
+    before, free_before = torch.cuda.memory_allocated(), torch.cuda.mem_get_info()[0]
+    assert lib.pr_depth_order_static(C, N, _ptr(depths), _ptr(got), stream) == 0
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() == before
+    if _both.warm:
+        assert torch.cuda.mem_get_info()[0] >= free_before, "device memory was allocated inside the call"
+    _both.warm = True
     return got, want
+
+
+_both.warm = False
 
 
 def test_depth_order_without_allocation_matches_the_scratch_buffer_entry_point(gpu):
