@@ -153,13 +153,18 @@ def pmc_record(workload_key):
     return rec if rec.get("workload") == workload_key else {}
 
 
-def pair_counts(workload_key):
-    """Iteration counts of the backward compositor from the diagnostic build (profiles/r02_bwd_pair_counts.json)."""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_bwd_pair_counts.json")))
-    except Exception:
-        return None
-    return rec if rec.get("workload") == workload_key else None
+def pair_counts(workload_key, pixels_per_lane):
+    """Iteration counts of the backward compositor from a diagnostic build, for the kernel variant that ran
+    (profiles/r03_bwd_pair_counts.json: 8x8 regions; profiles/r02_bwd_pair_counts.json: half tiles)."""
+    for name in ("r03_bwd_pair_counts.json", "r02_bwd_pair_counts.json"):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        if rec.get("workload") == workload_key and rec.get("pixels_per_lane", 4) == pixels_per_lane:
+            rec["file"] = "profiles/" + name
+            return rec
+    return None
 
 
 def tracking_config(args, dev):
@@ -391,19 +396,24 @@ def main():
         fp32 = None
         fwd_plan = _lib.raster_plan(D, ts, n_tiles)
         bwd_plan = _lib.raster_plan(D, ts, n_tiles, backward=True)
-        diag = pair_counts(f"{N}x{W}x{H}xF{F}ts{ts}")
+        diag = pair_counts(f"{N}x{W}x{H}xF{F}ts{ts}", bwd_plan[0])
         if dom == "pr_raster_bwd" and diag:
             iters, half = diag["contributing_iters"], diag["half_tile_iters"]
-            region = ts * ts * diag.get("pixels_per_lane", 4) // 4     # pixels one wavefront covers
-            assert diag.get("pixels_per_lane", 4) == bwd_plan[0], "pair counts were taken with another kernel variant"
+            # pixels one wavefront covers: an 8x8 region for the matrix-core kernel, else ts*ts*ppl/4
+            region = diag.get("pixels_per_iteration", ts * ts * diag.get("pixels_per_lane", 4) // 4)
             pairs = (iters - half) * region + half * region / 2
             fma = 2 * D + 30
             flops = 2.0 * fma * pairs
-            fp32 = {"fma_per_pixel_pair": fma, "tile_gaussian_iterations": iters, "of_them_half_tile": half, "pixels_per_iteration": region,
-                    "pixel_pairs_evaluated": pairs, "pixel_pairs_contributing": diag["active_px_per_iter"] * iters,
+            fp32 = {"fma_per_pixel_pair": fma, "region_gaussian_iterations": iters, "of_them_half_tile": half,
+                    "pixels_per_iteration": region, "pixel_pairs_evaluated": pairs,
                     "achieved_tflops": flops / (avg_ms * 1e-3) / 1e12, "peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
                     "frac": flops / (avg_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
-                    "source": "profiles/r02_bwd_pair_counts.json (diagnostic build, view 0)"}
+                    "note": "the two channel contractions run as v_mfma_f32_16x16x4_f32, whose rate equals the packed "
+                            "vector rate (measured: matrix and vector instructions of one SIMD do not overlap)"
+                            if bwd_plan[2] else "all on the vector unit",
+                    "source": diag["file"] + " (diagnostic build, view 0)"}
+            if "active_px_per_iter" in diag:
+                fp32["pixel_pairs_contributing"] = diag["active_px_per_iter"] * iters
         out = {
             "metric": ("Mpix/s fwd+bwd (1M Gauss, 1080p, RGB+32ch feat)" if args.config == "cfg2" and not (
                 args.gaussians or args.width or args.height or args.features is not None or args.tile_size)
@@ -430,7 +440,8 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": pmc.get(dom),
-                "limited_by": "VALU issue (see fp32): the kernel moves well under what HBM could deliver",
+                "limited_by": "vector / float32 matrix instruction issue (see fp32): the kernel moves well under what HBM "
+                              "could deliver",
                 "measured_copy_peak_GBps": copy_peak_gbs(dev),
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch_gsplat_rule": per_stage_gsplat[dom] / (launches / args.steps),
@@ -460,6 +471,9 @@ def main():
             _lib.set_tuning(POGS_RAST_FWD_MFMA=cur if cur else None)
             variant("two_call", "unmodified-POGS call pattern: RGB+ED and the features as two rasterization() calls "
                                 "(pogs/pogs.py:352,493)", two_call=not args.two_call)
+            _lib.set_tuning(POGS_RAST_BWD_MFMA=0)
+            variant("bwd_vector_half_tiles", "backward on the vector unit, one wavefront per 16x8 half tile at 2 pixels "
+                    "per lane (raster_bwd_kernel): the default before the float32 matrix-core kernel")
             _lib.set_tuning(POGS_RAST_BWD_MFMA=3)
             variant("bwd_deferred_split_bf16", "backward: colour-gradient contraction of the first 32 channels deferred to "
                     "three bf16 matrix products per 16 contributing Gaussians (raster_bwd_cmfma_kernel), opt-in")
