@@ -203,12 +203,149 @@ def tracking_config(args, dev):
     }
 
 
+def pogs_step_config(args, dev):
+    """The training iteration POGS runs once its feature fields are active: three rasterization() calls on one scene
+    and one camera (pogs/pogs.py:352-371 RGB+ED at full resolution with absgrad; :419-437 the 96-channel hash-grid
+    encoding at half resolution, geometry and colour gradients, absgrad; :493-510 the 64 DINO channels at 450x250
+    with every geometry input detached), each followed by its backward pass.  The hash-grid output and the losses
+    are stood in for by a random [N,96] leaf and random cotangents."""
+    N, W, H, ts = args.gaussians or 1_000_000, args.width or 1920, args.height or 1080, args.tile_size or 16
+    n_views = max(args.views, 1)
+    sc = make_scene(N, W, H, n_features=64, n_views=n_views, seed=0)
+    g = torch.Generator().manual_seed(7)
+    params = {"means": sc.means, "quats": sc.quats, "log_scales": sc.log_scales, "opacity_logits": sc.opacity_logits,
+              "sh": sc.sh, "dino": sc.features, "clip": torch.randn(N, 96, generator=g) * 0.5}
+    params = {k: v.to(dev).contiguous().requires_grad_(True) for k, v in params.items()}
+    viewmats, Ks = sc.viewmats.to(dev).contiguous(), sc.Ks.to(dev).contiguous()
+    W2, H2, W3, H3 = W // 2, H // 2, 450 * W // 1920, 250 * H // 1080
+    Ks2, Ks3 = Ks.clone(), Ks.clone()
+    Ks2[:, :2, :] *= 0.5
+    Ks3[:, :2, :] *= W3 / W
+    calls = [
+        dict(name="rgb_ed", channels=4, width=W, height=H, geometry=True, what="SH-RGB(deg 3)+ED, absgrad"),
+        dict(name="clip_96", channels=96, width=W2, height=H2, geometry=True, what="96 channels, geometry + colour "
+             "gradients, absgrad"),
+        dict(name="dino_64", channels=64, width=W3, height=H3, geometry=False, what="64 channels, colour gradients only"),
+    ]
+    cot = [torch.randn(1, c["height"], c["width"], c["channels"], generator=g).to(dev) for c in calls]
+    cot_alpha = torch.randn(1, H, W, 1, generator=g).to(dev)
+    info = {"counter": 0, "isects": [[], [], []]}
+
+    def render(k, view):
+        vm = viewmats[view:view + 1]
+        scales, opac = torch.exp(params["log_scales"]), torch.sigmoid(params["opacity_logits"])
+        common = dict(viewmats=vm, tile_size=ts, packed=False, near_plane=0.01, far_plane=1e10, sparse_grad=False,
+                      rasterize_mode="classic")
+        if k == 0:
+            r, a, meta = rendering.rasterization(means=params["means"], quats=params["quats"], scales=scales,
+                                                 opacities=opac, colors=params["sh"], sh_degree=3, Ks=Ks[view:view + 1],
+                                                 width=W, height=H, render_mode="RGB+ED", absgrad=True, **common)
+            torch.autograd.backward([r, a], [cot[0], cot_alpha])
+        elif k == 1:
+            r, a, meta = rendering.rasterization(means=params["means"], quats=params["quats"], scales=scales,
+                                                 opacities=opac, colors=params["clip"], Ks=Ks2[view:view + 1],
+                                                 width=W2, height=H2, render_mode="RGB", absgrad=True, **common)
+            torch.autograd.backward([r], [cot[1]])
+        else:
+            r, a, meta = rendering.rasterization(means=params["means"].detach(), quats=params["quats"].detach(),
+                                                 scales=scales.detach(), opacities=opac.detach(), colors=params["dino"],
+                                                 Ks=Ks3[view:view + 1], width=W3, height=H3, render_mode="RGB",
+                                                 absgrad=False, **common)
+            torch.autograd.backward([r], [cot[2]])
+        info["isects"][k].append(meta["n_composited_isects"])
+
+    def step(only=None):
+        i = info["counter"]
+        info["counter"] = i + 1
+        for p in params.values():
+            p.grad = None
+        for k in range(3):
+            if only is None or only == k:
+                render(k, i % n_views)
+
+    t_setup, n_setup = time.perf_counter(), 0
+    while n_setup < n_views or (time.perf_counter() - t_setup < args.precondition_s and n_setup < 1000):
+        step()
+        n_setup += 1
+        if n_setup % 8 == 0:
+            torch.cuda.synchronize()
+    info["counter"] = 0
+    for _ in range(args.warmup):
+        step()
+    for lst in info["isects"]:
+        lst.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = (time.perf_counter() - t0) / args.steps
+    isects = [sum(lst) / len(lst) for lst in info["isects"]]
+
+    # per call: its own timed pass (wall clock), then a pass with HIP events around every entry point
+    per_call = []
+    for k, c in enumerate(calls):
+        for _ in range(2):
+            step(only=k)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(only=k)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) / args.steps * 1e3
+        timer = rendering.StageTimer()
+        rendering.set_stage_timer(timer)
+        for _ in range(args.steps):
+            step(only=k)
+        torch.cuda.synchronize()
+        rendering.set_stage_timer(None)
+        stages = {n: v[1] / args.steps for n, v in timer.summary().items()}
+        D, n_tiles = c["channels"], math.ceil(c["width"] / ts) * math.ceil(c["height"] / ts)
+        plan_f = _lib.raster_plan(D, ts, n_tiles)
+        plan_b = _lib.raster_plan(D, ts, n_tiles, backward=True, geom_grad=c["geometry"])
+        per_call.append({
+            "call": c["name"], "what": c["what"], "width": c["width"], "height": c["height"], "channels": D,
+            "ms_alone": ms, "n_isects_composited": isects[k],
+            "kernels": {"fwd": {"pixels_per_lane": plan_f[0], "channels_per_pass": plan_f[1], "matrix_cores": plan_f[2]},
+                        "bwd": {"pixels_per_lane": plan_b[0], "channels_per_pass": plan_b[1], "matrix_cores": plan_b[2]}},
+            "stages_ms": {n: round(v, 4) for n, v in sorted(stages.items(), key=lambda kv: -kv[1])}})
+    # roofline of the slowest compositing launch of the step
+    k_dom, dom = max(((k, n) for k in range(3) for n in ("pr_raster_fwd", "pr_raster_bwd")),
+                     key=lambda kn: per_call[kn[0]]["stages_ms"].get(kn[1], 0.0))
+    c = calls[k_dom]
+    D, P = c["channels"], c["width"] * c["height"]
+    n_tiles = math.ceil(c["width"] / ts) * math.ceil(c["height"] / ts)
+    per_stage, _ = stage_bytes(N, 1, isects[k_dom], P, 16, 0, D, 32 + n_tiles.bit_length())
+    dom_bytes = per_stage[dom]
+    if dom == "pr_raster_bwd" and not c["geometry"]:
+        dom_bytes -= isects[k_dom] * 32       # no geometry gradient rows written
+    avg_ms = per_call[k_dom]["stages_ms"][dom]
+    achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
+    pixels = sum(cc["width"] * cc["height"] for cc in calls)
+    return {
+        "metric": "Mpix/s fwd+bwd over the three renders of a POGS training iteration (1M Gauss; 1080p RGB+ED, "
+                  "960x540x96ch, 450x250x64ch)",
+        "value": pixels / elapsed / 1e6, "unit": "Mpix/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "pogs_step: %d Gaussians, one camera per step cycling over %d ring cameras, three "
+                               "rasterization() calls each followed by its backward pass" % (N, n_views),
+                   "gaussians": N, "tile_size": ts, "calls": per_call,
+                   "sum_of_calls_alone_ms": sum(pc["ms_alone"] for pc in per_call)},
+        "roofline": {"bound": "hbm", "kernel": "%s of call %s" % (dom, c["name"]), "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms,
+                     "limited_by": "vector / float32 matrix instruction issue"},
+        "cpu_baseline": None,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS) + ["cfg3"])
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS) + ["cfg3", "pogs_step"])
     ap.add_argument("--gaussians", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -221,6 +358,12 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the extra timed passes (other kernel variants)")
     ap.add_argument("--two-call", action="store_true",
                     help="render RGB+ED and the features as two gsplat-signature calls instead of one fused call")
+    ap.add_argument("--with-optimizer", action="store_true",
+                    help="N = 1: run the step with the gradient exchange object of N > 1 (no collective with one rank, "
+                         "the fused Adam on the whole parameters), like for like with the multi-GPU step")
+    ap.add_argument("--lr-scale", type=float, default=0.0,
+                    help="factor on the reference's learning rates inside the benchmark (0: the optimiser does all its "
+                         "work but the parameters, and with them the intersection counts, stay those of step 0)")
     ap.add_argument("--exchange", default="sharded", choices=["sharded", "allreduce"],
                     help="N > 1: reduce-scatter + all-gather of the gradients in overlapped buckets, or one mean "
                          "all-reduce per large gradient after the backward pass")
@@ -246,6 +389,11 @@ def main():
             raise SystemExit("cfg3 (tracking) is single-GPU in the reference: run replicas, not ranks")
         print(json.dumps(tracking_config(args, dev)), flush=True)
         return
+    if args.config == "pogs_step":
+        if world != 1:
+            raise SystemExit("pogs_step is measured on one GPU")
+        print(json.dumps(pogs_step_config(args, dev)), flush=True)
+        return
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("POGS_BENCH_BACKEND", "nccl")   # "gloo" for a rehearsal on a shared GPU
@@ -268,7 +416,9 @@ def main():
     Ks = sc.Ks.to(dev).contiguous()
     # Multi-GPU: the gradients are exchanged every step (mean over ranks).  Single GPU: plain
     # zero_grad(set_to_none=True) semantics, as the reference's trainer does between iterations.
-    grads = make_exchange(args.exchange, params) if world > 1 else None
+    # --with-optimizer: the same object with one rank (its collectives drop out, the fused Adam runs on everything).
+    ex = {"grads": make_exchange(args.exchange, params, lr_scale=args.lr_scale)
+          if world > 1 or args.with_optimizer else None}
     D = 3 + F + 1
     g = torch.Generator().manual_seed(100 + rank)
     v_colors = torch.randn(1, H, W, D, generator=g).to(dev)
@@ -282,6 +432,7 @@ def main():
         viewmat, K = viewmats[view:view + 1], Ks[view:view + 1]
         for p in params.values():   # autograd adopts the gradient tensors the kernels produce
             p.grad = None
+        grads = ex["grads"]
         if grads is not None:   # the forward waits for each parameter of the previous exchange where it first reads it
             grads.begin_step(wait=["means", "quats", "log_scales", "opacity_logits"])
         scales = torch.exp(params["log_scales"])
@@ -359,10 +510,11 @@ def main():
         step()
     torch.cuda.synchronize()
     rendering.set_stage_timer(None)
-    if world > 1:
-        if grads is not None:
-            grads.wait_all()
+    grads = ex["grads"]
+    if grads is not None:
+        grads.wait_all()
         torch.cuda.synchronize()
+    if world > 1:
         dist.barrier()
 
     if rank == 0:
@@ -435,7 +587,10 @@ def main():
                                     "matrix_cores": fwd_plan[2]},
                             "bwd": {"pixels_per_lane": bwd_plan[0], "channels_per_pass": bwd_plan[1],
                                     "matrix_cores": bwd_plan[2]}},
-                "parallelism": ("camera-sharded dp%d, %s" % (world, grads.describe())) if world > 1 else "single GPU",
+                "parallelism": ("camera-sharded dp%d, %s" % (world, grads.describe())) if world > 1 else (
+                    "single GPU" + (", optimiser step inside the timed region: " + grads.describe()
+                                    if grads is not None else "")),
+                "optimizer_in_step": grads is not None, "lr_scale": args.lr_scale if grads is not None else None,
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -484,6 +639,14 @@ def main():
             rendering.set_count_speculation(False)
             variant("no_count_speculation", "every call waits on the host for its intersection count, as gsplat does")
             rendering.set_count_speculation(True)
+            if ex["grads"] is None and args.exchange == "sharded":
+                ex["grads"] = make_exchange(args.exchange, params, lr_scale=args.lr_scale)
+                variant("with_optimizer", "the N > 1 step on one GPU: gradient buckets -> fused Adam (learning rates x %g) "
+                        "-> parameters, launched from autograd hooks; compare the N > 1 lines with this one" %
+                        args.lr_scale)
+                ex["grads"].wait_all()
+                torch.cuda.synchronize()
+                ex["grads"] = None
             out["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, F, ts)
@@ -496,4 +659,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:   # a failed collective (or anything else): say so and leave with a failure status
+        import traceback
+        traceback.print_exc()
+        print(json.dumps({"error": "%s: %s" % (type(exc).__name__, exc), "rank": os.environ.get("RANK", "0")}),
+              file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        os._exit(1)     # not sys.exit: a rank stuck in a collective's destructor must not keep the job alive

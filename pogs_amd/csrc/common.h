@@ -39,6 +39,7 @@ constexpr int WAVE = 64;
 struct Tuning {
   int fwd_ppl;      // POGS_RAST_FWD_PPL: force 1/2/4 pixels per lane in the forward compositor (0 = planner)
   int fwd_chunk;    // POGS_RAST_FWD_CHUNK: widest forward channel pass (0 = planner)
+  int fwd_blocks;   // POGS_RAST_FWD_BLOCKS: 1 = forward compositor with per-4x4-block walks (16x16 tiles), 0 = never, -1 = planner
   int fwd_mfma;     // POGS_RAST_FWD_MFMA: 1 = split-bf16 matrix-core colour accumulation for 32..72-channel passes
   int bwd_ppl;      // POGS_RAST_BWD_PPL: as fwd_ppl for the backward compositor
   int bwd_mfma;     // POGS_RAST_BWD_MFMA: -1 (unset) = planner: the float32 matrix-core kernel on 8x8 regions wherever it wins,
@@ -150,9 +151,9 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;  // smallest alpha the compositor let
 // the region can see.  If even that is below 1/255 the Gaussian cannot contribute to this region (the
 // square 3-sigma bounding box that built the tile lists is far looser for elongated or faint Gaussians).
 // Conservative by a margin of 1e-3 in the exponent; non-positive-definite conics are always kept.
-__device__ __forceinline__ bool touches_region(float gx, float gy, float o, float a, float b, float c, float rx0,
-                                               float ry0, float rx1, float ry1) {
-  if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return true;
+// Smallest value of sigma = (a dx^2 + c dy^2)/2 + b dx dy over the rectangle, for a positive definite conic.
+__device__ __forceinline__ float min_sigma_in_rect(float gx, float gy, float a, float b, float c, float rx0, float ry0,
+                                                   float rx1, float ry1) {
   const float xl = rx0 - gx, xr = rx1 - gx, yl = ry0 - gy, yr = ry1 - gy;
   const float X = fminf(fmaxf(0.f, xl), xr), Y = fminf(fmaxf(0.f, yl), yr);  // nearest rectangle point per axis
   float smin = 0.f;
@@ -168,7 +169,21 @@ __device__ __forceinline__ bool touches_region(float gx, float gy, float o, floa
     }
     smin = fmaxf(fminf(s1, s2), 0.f);
   }
+  return smin;
+}
+__device__ __forceinline__ bool touches_region(float gx, float gy, float o, float a, float b, float c, float rx0,
+                                               float ry0, float rx1, float ry1) {
+  if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return true;
+  const float smin = min_sigma_in_rect(gx, gy, a, b, c, rx0, ry0, rx1, ry1);
   return o * __builtin_amdgcn_exp2f(1e-3f - smin * LOG2E) >= ALPHA_MIN;
+}
+// The same test for a conic that is already multiplied by log2(e) (al = a log2e, ...), as the compositors' staged
+// records hold it.
+__device__ __forceinline__ bool touches_region_log2(float gx, float gy, float o, float al, float bl, float cl, float rx0,
+                                                    float ry0, float rx1, float ry1) {
+  if (!(al > 0.f && cl > 0.f && al * cl - bl * bl > 0.f)) return true;
+  const float smin = min_sigma_in_rect(gx, gy, al, bl, cl, rx0, ry0, rx1, ry1);
+  return o * __builtin_amdgcn_exp2f(1e-3f - smin) >= ALPHA_MIN;
 }
 
 __device__ __forceinline__ float wave_sum_all(float v) {

@@ -211,6 +211,15 @@ int launch_bwd_mm(int cd, int tile_size, bool geom_grad, bool color_grad, bool s
                   const float *v_render_colors, const float *v_render_alphas, int absgrad, float *v_geom,
                   const GradSegs &gs, hipStream_t stream);
 
+// raster_fwd_blocks.hip: forward compositor on 16x16 tiles whose wavefronts (one per half tile) walk a list per 4x4
+// pixel block; passes of up to 48 channels, all passes of a call in one launch
+bool fwd_blocks_supports(int cd, int tile_size);
+int launch_fwd_blocks(int cd, int C, int N, int D, int ch_off, int per, int n_pass, const float *means2d,
+                      const float *conics, const ColorSegs &cs, const float *opacities, const float *backgrounds, int width,
+                      int height, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
+                      const int32_t *flatten_ids, int64_t n_isects, int ed_channel, float *render_colors,
+                      float *render_alphas, int32_t *last_ids, hipStream_t stream);
+
 // The geometry of one batch of up to 64 intersections, one per lane, loaded ahead of time: the ids and the
 // records they point to are two dependent global round trips, which the caller issues a whole batch early
 // (right after staging the previous one) so that only the colour rows remain to be fetched at staging time.
@@ -239,6 +248,49 @@ __device__ __forceinline__ BatchGeometry prefetch_batch(int lane, int first, int
   return b;
 }
 
+// Copy the CD channels from ch_off on of Gaussian g (flat index) from the colour tensors to `dst` (16-byte aligned,
+// round4(CD) floats); channels past D are written as zeros.
+template <int CD>
+__device__ __forceinline__ void stage_color_row(float *dst, int g, const ColorSegs &cs, int N, int D, int ch_off) {
+  int nch = D - ch_off;  // channels available from ch_off on
+  const float *src = cs.ptr[0] + (int64_t)g * cs.ld[0] + ch_off;
+  if (cs.n > 1 || cs.shared[0]) {
+    // channels gathered from several tensors: one pointer per segment, pre-offset so that [channel] indexes it
+    const int gn = g % N;
+    const float *b0 = cs.ptr[0] + (int64_t)(cs.shared[0] ? gn : g) * cs.ld[0] - cs.begin[0];
+    const float *b1 = cs.n > 1 ? cs.ptr[1] + (int64_t)(cs.shared[1] ? gn : g) * cs.ld[1] - cs.begin[1] : b0;
+    const float *b2 = cs.n > 2 ? cs.ptr[2] + (int64_t)(cs.shared[2] ? gn : g) * cs.ld[2] - cs.begin[2] : b0;
+#pragma unroll
+    for (int k = 0; k < round4(CD); k += 4) {
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = ch_off + k + i;
+        const float *b = ch >= cs.begin[2] ? b2 : ch >= cs.begin[1] ? b1 : b0;
+        v[i] = (k + i < nch) ? b[ch] : 0.f;
+      }
+      *reinterpret_cast<float4 *>(dst + k) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  } else if (((cs.ld[0] | ch_off) & 3) == 0) {
+#pragma unroll
+    for (int k = 0; k < round4(CD); k += 4) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < nch) v = *reinterpret_cast<const float4 *>(src + k);
+      *reinterpret_cast<float4 *>(dst + k) = v;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < round4(CD); k += 4) {
+      float4 v;
+      v.x = (k + 0 < nch) ? src[k + 0] : 0.f;
+      v.y = (k + 1 < nch) ? src[k + 1] : 0.f;
+      v.z = (k + 2 < nch) ? src[k + 2] : 0.f;
+      v.w = (k + 3 < nch) ? src[k + 3] : 0.f;
+      *reinterpret_cast<float4 *>(dst + k) = v;
+    }
+  }
+}
+
 // Stage a prefetched batch: lane j tests Gaussian j against the region and, if it can contribute, writes its
 // record and colour row to the wave's LDS slice.  Returns the wave-wide mask of staged Gaussians.
 template <int CD, bool BWD, int BS>
@@ -256,44 +308,7 @@ __device__ __forceinline__ unsigned long long stage_batch(
       L.g4[lane] = make_float4(xy.x, xy.y, o, -0.5f * LOG2E * ca);
       L.g2[lane] = make_float2(-LOG2E * cb, -0.5f * LOG2E * cc);
       L.ids[lane] = g;
-      int nch = D - ch_off;  // channels available from ch_off on
-      float *dst = L.col + lane * ROW;
-      const float *src = cs.ptr[0] + (int64_t)g * cs.ld[0] + ch_off;
-      if (cs.n > 1 || cs.shared[0]) {
-        // channels gathered from several tensors: one pointer per segment, pre-offset so that [channel] indexes it
-        const int gn = g % N;
-        const float *b0 = cs.ptr[0] + (int64_t)(cs.shared[0] ? gn : g) * cs.ld[0] - cs.begin[0];
-        const float *b1 = cs.n > 1 ? cs.ptr[1] + (int64_t)(cs.shared[1] ? gn : g) * cs.ld[1] - cs.begin[1] : b0;
-        const float *b2 = cs.n > 2 ? cs.ptr[2] + (int64_t)(cs.shared[2] ? gn : g) * cs.ld[2] - cs.begin[2] : b0;
-#pragma unroll
-        for (int k = 0; k < round4(CD); k += 4) {
-          float v[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int ch = ch_off + k + i;
-            const float *b = ch >= cs.begin[2] ? b2 : ch >= cs.begin[1] ? b1 : b0;
-            v[i] = (k + i < nch) ? b[ch] : 0.f;
-          }
-          *reinterpret_cast<float4 *>(dst + k) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      } else if (((cs.ld[0] | ch_off) & 3) == 0) {
-#pragma unroll
-        for (int k = 0; k < round4(CD); k += 4) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (k < nch) v = *reinterpret_cast<const float4 *>(src + k);
-          *reinterpret_cast<float4 *>(dst + k) = v;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < round4(CD); k += 4) {
-          float4 v;
-          v.x = (k + 0 < nch) ? src[k + 0] : 0.f;
-          v.y = (k + 1 < nch) ? src[k + 1] : 0.f;
-          v.z = (k + 2 < nch) ? src[k + 2] : 0.f;
-          v.w = (k + 3 < nch) ? src[k + 3] : 0.f;
-          *reinterpret_cast<float4 *>(dst + k) = v;
-        }
-      }
+      stage_color_row<CD>(L.col + lane * ROW, g, cs, N, D, ch_off);
     }
   }
   // Retire every staging load here.  Without this the compiler leaves some of them pending into the

@@ -457,11 +457,22 @@ static int pick_chunk(int want) {
 
 struct FwdPlan {
   int ppl, per;
+  bool blocks;  // the per-block-walk kernel (raster_fwd_blocks.hip): 2 pixels per lane, all passes in one launch
 };
+
+static bool plan_blocks(int tile_size) { return tile_size == 16 && tuning().fwd_blocks == 1 && tuning().fwd_ppl == 0; }
 
 // D channels -> chunk width and pixels per lane.  POGS_RAST_FWD_PPL / POGS_RAST_FWD_CHUNK override (tuning aid).
 static FwdPlan plan_fwd(int D, int tile_size, int64_t n_tiles_total) {
   FwdPlan p;
+  p.blocks = false;
+  if (plan_blocks(tile_size)) {
+    const int n_chunks = (D + 47) / 48;
+    p.per = ((D + n_chunks - 1) / n_chunks + 3) & ~3;
+    p.ppl = 2;
+    p.blocks = true;
+    return p;
+  }
   // Large images have tiles to spare: channel chunks of <= 48 keep 4 pixels per lane (alpha is recomputed
   // per chunk, which is cheaper than losing the per-Gaussian amortisation).  Small images take all channels
   // in one pass with fewer pixels per lane, which also doubles or quadruples the number of wavefronts.
@@ -497,7 +508,7 @@ extern "C" int pr_raster_fwd_plan(int D, int tile_size, int64_t n_tiles_total, i
   if (pixels_per_lane) *pixels_per_lane = plan.ppl;
   if (channels_per_pass) *channels_per_pass = plan.per;
   if (matrix_cores)
-    *matrix_cores = tuning().fwd_mfma != 0 && tile_size == 16 && cd >= 32 &&
+    *matrix_cores = !plan.blocks && tuning().fwd_mfma != 0 && tile_size == 16 && cd >= 32 &&
                     ((plan.ppl == 2 && cd <= 48) || (plan.ppl == 1 && cd <= 72));
   return PR_OK;
 }
@@ -533,6 +544,11 @@ extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const fl
   // Float32 accumulation (what gsplat's kernel does) unless the caller opts into the split-bf16 matrix-core
   // variant, whose error grows with the colour magnitude (about 1.2e-5 * max|colour|).
   const bool use_mfma = tuning().fwd_mfma != 0;
+  if (plan.blocks)
+    return launch_fwd_blocks(pick_chunk(min(plan.per, D)), C, N, D, 0, plan.per, (D + plan.per - 1) / plan.per, means2d,
+                             conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets, tile_order,
+                             flatten_ids, n_isects, ed_channel, render_colors, render_alphas, last_ids,
+                             (hipStream_t)stream);
   for (int off = 0; off < D; off += plan.per) {
     const int cd = pick_chunk(min(plan.per, D - off));
     int rc = PR_EUNSUPPORTED;

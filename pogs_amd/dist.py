@@ -551,11 +551,15 @@ REFERENCE_ADAM = {
 }
 
 
-def make_exchange(kind: str, params: Dict[str, Tensor], group=None):
-    """``"sharded"``: ``ShardedExchange`` with the fused Adam on the shards; ``"allreduce"``: mean all-reduce only."""
+def make_exchange(kind: str, params: Dict[str, Tensor], group=None, lr_scale: float = 1.0):
+    """``"sharded"``: ``ShardedExchange`` with the fused Adam on the shards; ``"allreduce"``: mean all-reduce only.
+    ``lr_scale`` multiplies the reference's learning rates (0 keeps the parameters where they are while the
+    optimiser still reads and writes everything: what a benchmark with a fixed workload wants)."""
     if kind == "allreduce":
         return _AllReduceExchange(params, group)
     if kind == "sharded":
-        cfg = {k: REFERENCE_ADAM.get(k, {"lr": 1e-3, "eps": 1e-15}) for k in params}
+        cfg = {k: dict(REFERENCE_ADAM.get(k, {"lr": 1e-3, "eps": 1e-15})) for k in params}
+        for c in cfg.values():
+            c["lr"] = c["lr"] * lr_scale
         return ShardedExchange(params, ShardAdam(cfg), group)
     raise ValueError(kind)

@@ -443,6 +443,86 @@ def test_raster_forward_forced_variants(gpu, tuning, ppl, D, mfma):
     assert_image_close(alpha, alpha_r, amb, "alpha")
 
 
+@pytest.mark.parametrize("D", [3, 4, 19, 36, 48, 65, 97, 100])
+@pytest.mark.parametrize("with_bg", [False, True])
+def test_raster_forward_block_walks(gpu, tuning, D, with_bg):
+    """The forward compositor whose wavefronts walk one list per 4x4 pixel block (POGS_RAST_FWD_BLOCKS=1; passes of up
+    to 48 channels, all in one launch): every pixel composites the same Gaussians in the same order with the same
+    arithmetic as in the vector kernel at 2 pixels per lane (whose lanes' two pixels also share one dx), so the images
+    must be IDENTICAL to that kernel's, bit for bit, besides agreeing with the float64 oracle; the backward pass that
+    follows reads the last-contributor table it wrote."""
+    rd = _rendering()
+    from pogs_amd import _lib
+
+    sc = small_scene(n=700, w=70, h=45, views=2, seed=5, lo=0.02, hi=0.3)   # ragged: 70x45 is not tile aligned
+    dev, offs, flat = _staged(gpu, sc, D, 16)
+    bg = torch.rand(2, D, generator=torch.Generator().manual_seed(2)).to(gpu) if with_bg else None
+    ed = D - 1 if D in (4, 36) else -1
+    tuning(POGS_RAST_FWD_BLOCKS=0, POGS_RAST_FWD_PPL=2, POGS_RAST_FWD_CHUNK=48)
+    ref_out, ref_alpha = rd.rasterize_to_pixels(dev["means2d"], dev["conics"], dev["colors"], dev["opacities"], sc.width,
+                                                sc.height, 16, offs, flat, backgrounds=bg, ed_channel=ed)
+    tuning(POGS_RAST_FWD_BLOCKS=1, POGS_RAST_FWD_PPL=None, POGS_RAST_FWD_CHUNK=None)
+    n_pass = (D + 47) // 48
+    assert _lib.raster_plan(D, 16, 2 * 5 * 3) == (2, ((D + n_pass - 1) // n_pass + 3) // 4 * 4, False)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in dev.items()}
+    out, alpha = rd.rasterize_to_pixels(leaves["means2d"], leaves["conics"], leaves["colors"], leaves["opacities"],
+                                        sc.width, sc.height, 16, offs, flat, backgrounds=bg, ed_channel=ed)
+    assert torch.equal(out, ref_out), float((out - ref_out).detach().abs().max())
+    assert torch.equal(alpha, ref_alpha)
+    if ed < 0:
+        cpu, out_r, alpha_r, amb = _oracle_raster(dev, offs, flat, sc, 16, bg, True)
+        assert_image_close(out, out_r, amb, f"colors D={D}, block walks")
+        assert_image_close(alpha, alpha_r, amb, "alpha")
+        g = torch.Generator().manual_seed(13)
+        keep = (~amb)[..., None].float()
+        vc, va = torch.randn(out_r.shape, generator=g) * keep, torch.randn(alpha_r.shape, generator=g) * keep
+        (out_r * vc.double()).sum().add((alpha_r * va.double()).sum()).backward()
+        ((out * vc.to(gpu)).sum() + (alpha * va.to(gpu)).sum()).backward()
+        for k in ("colors", "opacities", "conics", "means2d"):
+            assert_grad_close(leaves[k].grad, cpu[k].grad, f"{k} D={D} after the block-walk forward")
+
+
+@pytest.mark.parametrize("shape", ["many faint Gaussians on one tile", "200k Gaussians at 1024x768"])
+def test_raster_forward_block_walks_long_lists(gpu, tuning, shape):
+    """Lists far longer than the ring of staged entries (and, in the first scene, more staged entries on one half tile
+    than the 16-bit entry numbers of the per-block lists count before they wrap): identical images again, through the
+    whole rasterization() call -- the second scene with SH colours, expected depth and features from three tensors."""
+    rd = _rendering()
+    if shape.startswith("many"):
+        n, W, H, D = 150_000, 40, 24, 8
+        g = torch.Generator().manual_seed(5)
+        means2d = (torch.rand(1, n, 2, generator=g) * torch.tensor([16.0, 8.0]) + torch.tensor([16.0, 8.0]))
+        conics = torch.tensor([0.6, 0.05, 0.5]).expand(1, n, 3).contiguous()
+        opac = torch.full((1, n), 0.0045)          # 1/255 = 0.0039: alive near the centre only, never saturating
+        colors = torch.rand(1, n, D, generator=g)
+        offs = torch.zeros(1, 2, 3, dtype=torch.int32)
+        offs[0, 0, 2:] = n                          # every entry on tile (0, 1), whose pixels are x 16..31, y 0..15
+        offs[0, 1, :] = n
+        flat = torch.arange(n, dtype=torch.int32)
+        args = [t.to(gpu) for t in (means2d, conics, colors, opac)]
+        outs = []
+        for blocks in (0, 1):
+            tuning(POGS_RAST_FWD_BLOCKS=blocks, POGS_RAST_FWD_PPL=None if blocks else 2)
+            outs.append(rd.rasterize_to_pixels(*args, W, H, 16, offs.to(gpu), flat.to(gpu)))
+        assert float(outs[0][1].max()) > 0.5
+    else:
+        from pogs_amd.scenes import make_scene
+        W, H, F = 1024, 768, 32
+        sc = make_scene(200_000, W, H, n_features=F, seed=2)
+        outs = []
+        for blocks in (0, 1):
+            tuning(POGS_RAST_FWD_BLOCKS=blocks, POGS_RAST_FWD_PPL=None if blocks else 2)
+            with torch.no_grad():
+                r, a, meta = rd.rasterization(sc.means.to(gpu), sc.quats.to(gpu), sc.log_scales.exp().to(gpu),
+                                              torch.sigmoid(sc.opacity_logits).to(gpu), sc.sh.to(gpu),
+                                              sc.viewmats.to(gpu), sc.Ks.to(gpu), W, H, sh_degree=3, render_mode="RGB+ED",
+                                              packed=False, tile_size=16, features=sc.features.to(gpu))
+            outs.append((r, a))
+        assert meta["flatten_ids"].numel() > 100 * 3072
+    assert torch.equal(outs[0][0], outs[1][0]), float((outs[0][0] - outs[1][0]).abs().max())
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (10.0, 0.0), (100.0, 0.0), (1.0, 50.0)])
 @pytest.mark.parametrize("ppl", [2, 1])
 def test_raster_forward_precision_does_not_depend_on_colour_magnitude(gpu, tuning, scale, offset, ppl):
