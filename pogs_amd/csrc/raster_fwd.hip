@@ -11,7 +11,7 @@ constexpr int fwd_waves_per_simd(int ppl, int cd) { return (ppl == 2 && cd > 32 
 
 template <int TS, int PPL, int CD>
 __global__ void __launch_bounds__(64 * WPB, fwd_waves_per_simd(PPL, CD)) raster_fwd_kernel(
-    int n_regions, int N, int D, int ch_off, const float *__restrict__ means2d, const float *__restrict__ conics,
+    int n_regions, int N, int D, int ch_off0, int per, const float *__restrict__ means2d, const float *__restrict__ conics,
     const ColorSegs cs, const float *__restrict__ opacities, const float *__restrict__ backgrounds,
     int width, int height, int tile_w, int tile_h, const int32_t *__restrict__ isect_offsets,
     const int32_t *__restrict__ tile_order, const int32_t *__restrict__ flatten_ids, int n_isects, int ed_channel, float *__restrict__ render_colors,
@@ -25,6 +25,8 @@ __global__ void __launch_bounds__(64 * WPB, fwd_waves_per_simd(PPL, CD)) raster_
   __shared__ WaveLds<CD, false, BS> lds[WPB];
   static_assert(WPB == 1, "one wavefront per workgroup");
   const int lane = threadIdx.x & 63;
+  // the channel passes of a call are the rows of the grid: on a small image one pass alone leaves SIMDs idle
+  const int ch_off = ch_off0 + (int)blockIdx.y * per;
   const RegionId rid = region_of<Rg::WPT>(tile_order, n_regions);
   if (!rid.valid) return;
   WaveLds<CD, false, BS> &L = lds[0];
@@ -430,15 +432,15 @@ static int launch_fwd_mfma(int C, int N, int D, int ch_off, const float *means2d
 }
 
 template <int TS, int PPL, int CD>
-static int launch_fwd(int C, int N, int D, int ch_off, const float *means2d, const float *conics, const ColorSegs &cs,
+static int launch_fwd(int C, int N, int D, int ch_off, int per, int n_pass, const float *means2d, const float *conics, const ColorSegs &cs,
                       const float *opacities, const float *backgrounds, int width, int height, int tile_w, int tile_h,
                       const int32_t *isect_offsets, const int32_t *tile_order, const int32_t *flatten_ids,
                       int64_t n_isects, int ed_channel,
                       float *render_colors, float *render_alphas, int32_t *last_ids, hipStream_t stream) {
   const int64_t n_regions = (int64_t)C * tile_w * tile_h * Region<TS, PPL>::WPT;
   const unsigned grid = region_grid(n_regions, Region<TS, PPL>::WPT, tile_order != nullptr);
-  hipLaunchKernelGGL((raster_fwd_kernel<TS, PPL, CD>), dim3(grid), dim3(64 * WPB), 0, stream, (int)n_regions, N, D, ch_off,
-                     means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
+  hipLaunchKernelGGL((raster_fwd_kernel<TS, PPL, CD>), dim3(grid, n_pass), dim3(64 * WPB), 0, stream, (int)n_regions, N, D,
+                     ch_off, per, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,
                      tile_order, flatten_ids, (int)n_isects, ed_channel, render_colors, render_alphas, last_ids);
   return check_launch("raster_fwd_kernel");
 }
@@ -473,11 +475,21 @@ static FwdPlan plan_fwd(int D, int tile_size, int64_t n_tiles_total) {
     p.blocks = true;
     return p;
   }
-  // Large images have tiles to spare: channel chunks of <= 48 keep 4 pixels per lane (alpha is recomputed
-  // per chunk, which is cheaper than losing the per-Gaussian amortisation).  Small images take all channels
-  // in one pass with fewer pixels per lane, which also doubles or quadruples the number of wavefronts.
+  // Large images have tiles to spare: passes of <= 48 channels keep the accumulators of two pixels per lane within four
+  // wavefronts per SIMD (alpha is recomputed per pass, which is cheaper than losing that).  A small image has too few
+  // tiles to fill the chip with one wavefront per region, and every wavefront is one long dependent chain down its
+  // tile's list: there the passes, which run side by side as rows of one launch, are made narrower until the launch
+  // has about six thousand wavefronts -- <= 32 channels, or <= 16 on the smallest images.  Measured (forward kernel
+  // alone, one pass of all channels -> this rule): 1M Gaussians at 960x540 with 96 channels 0.73 -> 0.51 ms; at 450x250
+  // with 64 channels 0.37 -> 0.27 ms; 200k Gaussians at 640x360 with 64 channels 0.23 -> 0.23 ms.
   const bool many_tiles = tile_size == 16 && n_tiles_total >= 3072;
-  const int max_chunk = tuning().fwd_chunk > 0 ? tuning().fwd_chunk : many_tiles ? 48 : 100;
+  int max_chunk = many_tiles ? 48 : 100;
+  if (tile_size == 16 && !many_tiles && D > 32) {
+    max_chunk = 32;
+    const int64_t regions = n_tiles_total * (n_tiles_total < 1536 ? 4 : 2);  // wavefronts of one pass (see ppl below)
+    if (regions * ((D + 31) / 32) < 6000) max_chunk = 16;
+  }
+  if (tuning().fwd_chunk > 0) max_chunk = tuning().fwd_chunk;
   const int n_chunks = (D + max_chunk - 1) / max_chunk;
   p.per = ((D + n_chunks - 1) / n_chunks + 3) & ~3;
   if (tile_size == 8) {
@@ -516,9 +528,13 @@ extern "C" int pr_raster_fwd_plan(int D, int tile_size, int64_t n_tiles_total, i
 #define FWD_ARGS                                                                                                    \
   C, N, D, off, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets,          \
       tile_order, flatten_ids, n_isects, ed_channel, render_colors, render_alphas, last_ids, (hipStream_t)stream
+#define FWD_ARGS_V                                                                                                  \
+  C, N, D, off, plan.per, n_pass, means2d, conics, cs, opacities, backgrounds, width, height, tile_w, tile_h,        \
+      isect_offsets, tile_order, flatten_ids, n_isects, ed_channel, render_colors, render_alphas, last_ids,          \
+      (hipStream_t)stream
 #define FWD_CASE(TS, PPL, CDV) \
   case CDV:                    \
-    rc = launch_fwd<TS, PPL, CDV>(FWD_ARGS); \
+    rc = launch_fwd<TS, PPL, CDV>(FWD_ARGS_V); \
     break;
 
 extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const float *conics, const float *colors,
@@ -549,8 +565,14 @@ extern "C" int pr_raster_fwd(int C, int N, int D, const float *means2d, const fl
                              conics, cs, opacities, backgrounds, width, height, tile_w, tile_h, isect_offsets, tile_order,
                              flatten_ids, n_isects, ed_channel, render_colors, render_alphas, last_ids,
                              (hipStream_t)stream);
-  for (int off = 0; off < D; off += plan.per) {
-    const int cd = pick_chunk(min(plan.per, D - off));
+  const int cd_all = pick_chunk(min(plan.per, D));
+  const bool pass_mfma = use_mfma && tile_size == 16 && plan.ppl != 4 && cd_all >= 32 &&
+                         ((plan.ppl == 2 && cd_all <= 48) || (plan.ppl == 1 && cd_all <= 72));
+  // The vector kernels take all passes of the call in one launch (the passes are rows of the grid, all compiled for
+  // the width of the first); the matrix-core variant goes pass by pass.
+  for (int off = 0; off < D; off += pass_mfma ? plan.per : D) {
+    const int cd = pass_mfma ? pick_chunk(min(plan.per, D - off)) : cd_all;
+    const int n_pass = (D + plan.per - 1) / plan.per;
     int rc = PR_EUNSUPPORTED;
     if (tile_size == 8) {
       switch (cd) {

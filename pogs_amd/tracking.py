@@ -148,9 +148,15 @@ class TrackingLoop:
         angle = torch.atan2(sc.means[:, 1], sc.means[:, 0]) + math.pi
         labels = torch.clamp((angle / (2 * math.pi) * groups).long(), max=groups - 1)
         feats = torch.sin(sc.means @ (torch.randn(3, 64, generator=g) * 2.0) + torch.rand(64, generator=g) * 6.28)
+        from .mlp import FeatureMLP
+
+        with torch.random.fork_rng(devices=[dev]):   # the channel MLP's random weights are part of the seeded scene
+            torch.manual_seed(seed + 2)
+            net = FeatureMLP(device=dev)
         self = cls(sc.means.to(dev), torch.nn.functional.normalize(sc.quats, dim=-1).to(dev),
                    sc.log_scales.exp().to(dev), torch.sigmoid(sc.opacity_logits).to(dev), sc.sh.to(dev),
-                   feats.to(dev), labels.to(dev), groups, sc.viewmats[:1].to(dev), sc.Ks[:1].to(dev), width, height)
+                   feats.to(dev), labels.to(dev), groups, sc.viewmats[:1].to(dev), sc.Ks[:1].to(dev), width, height,
+                   mlp=net)
         moved = torch.zeros(groups, 7)
         moved[:, :3] = torch.randn(groups, 3, generator=g) * offset
         moved[:, 3] = 1.0

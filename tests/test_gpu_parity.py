@@ -429,7 +429,8 @@ def test_raster_forward_forced_variants(gpu, tuning, ppl, D, mfma):
     rd = _rendering()
     from pogs_amd import _lib
 
-    tuning(POGS_RAST_FWD_PPL=ppl, POGS_RAST_FWD_MFMA=mfma, POGS_RAST_FWD_CHUNK=48 if ppl == 4 or D > 72 else None)
+    # (the pass width is forced as well: left alone, an image this small goes in passes of 16 channels)
+    tuning(POGS_RAST_FWD_PPL=ppl, POGS_RAST_FWD_MFMA=mfma, POGS_RAST_FWD_CHUNK=48 if ppl == 4 or D > 72 else 100)
     sc = small_scene(n=700, w=70, h=45, views=2, seed=5, lo=0.02, hi=0.3)
     got_ppl, per, on_matrix = _lib.raster_plan(D, 16, 2 * 5 * 3)
     assert got_ppl == ppl, (got_ppl, per)
@@ -523,6 +524,20 @@ def test_raster_forward_block_walks_long_lists(gpu, tuning, shape):
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+def test_forward_planner_narrows_the_passes_on_small_images(gpu, tuning):
+    """Few tiles: the channel passes (rows of one launch) get narrower so that the launch fills the chip; many tiles:
+    passes of up to 48 channels at two pixels per lane.  (tiles of the 1080p, 960x540, 640x360 and 450x250 renders)"""
+    from pogs_amd import _lib
+
+    tuning(POGS_RAST_FWD_PPL=None, POGS_RAST_FWD_CHUNK=None, POGS_RAST_FWD_MFMA=None, POGS_RAST_FWD_BLOCKS=None)
+    assert _lib.raster_plan(36, 16, 120 * 68) == (2, 36, False)
+    assert _lib.raster_plan(100, 16, 120 * 68) == (2, 36, False)
+    assert _lib.raster_plan(96, 16, 60 * 34) == (2, 32, False)
+    assert _lib.raster_plan(64, 16, 40 * 23) == (1, 32, False)
+    assert _lib.raster_plan(64, 16, 29 * 16) == (1, 16, False)
+    assert _lib.raster_plan(32, 16, 29 * 16) == (1, 32, False)
+
+
 @pytest.mark.parametrize("scale,offset", [(1.0, 0.0), (10.0, 0.0), (100.0, 0.0), (1.0, 50.0)])
 @pytest.mark.parametrize("ppl", [2, 1])
 def test_raster_forward_precision_does_not_depend_on_colour_magnitude(gpu, tuning, scale, offset, ppl):
@@ -541,7 +556,7 @@ def test_raster_forward_precision_does_not_depend_on_colour_magnitude(gpu, tunin
     cmax = float(dev["colors"].abs().max())
     worst = {}
     for mfma in ("0", "1"):
-        tuning(POGS_RAST_FWD_PPL=ppl, POGS_RAST_FWD_MFMA=mfma)
+        tuning(POGS_RAST_FWD_PPL=ppl, POGS_RAST_FWD_MFMA=mfma, POGS_RAST_FWD_CHUNK=100)
         out, alpha = rd.rasterize_to_pixels(dev["means2d"], dev["conics"], dev["colors"], dev["opacities"], sc.width,
                                             sc.height, 16, offs, flat)
         err = (out.double().cpu() - out_r).abs().amax(-1)
