@@ -100,12 +100,23 @@ class TrackingLoop:
     Gaussian blur of the rendered features (``:304``) is left to the caller: it is not part of this path.
 
     Everything on one HIP device; appearance is frozen, so the compositor's backward runs without colour gradients.
+
+    ``set_rois`` switches to the per-object branch (``use_roi``, the reference config's default, ``:42`` and
+    ``:309-364``): one crop camera per rigid group (``observation.py:157-174``: the box in pixels, sides cut to
+    multiples of the 14-pixel DINO patch, principal point shifted by the corner, rescaled when a side exceeds 490
+    pixels), and per iteration, for every group, a render of THAT group's Gaussians alone (``obj_id`` gather,
+    ``pogs/pogs.py:287-300``) through its crop camera; the losses run over the concatenated pixels of all crops, the
+    depth term over pixels that are covered (accumulation > 0.85), observed, not depth outliers and survive the 5x5 and
+    9x9 erosions (``:317-337``) and whose squared error stays under ``depth_ignore_threshold``^2 (``:384``).
     """
+
+    MAX_ROI_RESOLUTION = 490   # observation.py:117
+    DINO_PATCH = 14
 
     def __init__(self, means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, sh: Tensor, features: Tensor,
                  group_labels: Tensor, n_groups: int, viewmat: Tensor, K: Tensor, width: int, height: int, mlp=None,
                  pose_lr: float = 0.004, pose_lr_final: float = 0.0008, depth_loss_mult: float = 3.7,
-                 dataset_scale: float = 1.0, fused_transform: bool = True):
+                 dataset_scale: float = 1.0, fused_transform: bool = True, depth_ignore_threshold: float = 0.26):
         from .mlp import FeatureMLP
 
         dev = means.device
@@ -120,6 +131,8 @@ class TrackingLoop:
         self.net.train()        # no alpha cut inside the optimisation
         self.pose_lr, self.pose_lr_final = pose_lr, pose_lr_final
         self.depth_loss_mult, self.dataset_scale = depth_loss_mult, dataset_scale
+        self.depth_ignore_threshold = depth_ignore_threshold
+        self.rois = None       # per group: crop camera, Gaussian subset, observation
         # True: the group transform runs inside the projection kernels (rasterization(rigid=...)); False: as its own
         # pass over the model (apply_to_model), the reference's structure.  Same results either way.
         self.fused_transform = fused_transform
@@ -135,7 +148,7 @@ class TrackingLoop:
         self.target = None
 
     @classmethod
-    def synthetic(cls, dev, n=200_000, width=640, height=360, groups=4, seed=0, offset=0.02):
+    def synthetic(cls, dev, n=200_000, width=640, height=360, groups=4, seed=0, offset=0.02, rois=False):
         """A seeded scene of ``n`` Gaussians in ``groups`` rigid groups (angular sectors around the view axis, like
         separate objects), with features that vary smoothly over space (as learned DINO features do over a surface),
         observed after every group was moved by a small pose offset: the loop has something to recover."""
@@ -164,6 +177,21 @@ class TrackingLoop:
         moved[:, 3:] = torch.nn.functional.normalize(moved[:, 3:], dim=-1)
         with torch.no_grad():
             self.set_observation(*self.render(moved.to(dev))[:2])
+            if rois:   # per-object crops: the box of every group's projected Gaussians, inflated a little
+                uv = sc.means @ sc.viewmats[0, :3, :3].T + sc.viewmats[0, :3, 3]
+                uv = (uv[:, :2] / uv[:, 2:3]) * torch.stack([sc.Ks[0, 0, 0], sc.Ks[0, 1, 1]]) + sc.Ks[0, :2, 2]
+                boxes = []
+                for g_ in range(groups):
+                    sel = uv[(labels == g_) & (uv[:, 0] > 0) & (uv[:, 0] < width) & (uv[:, 1] > 0) & (uv[:, 1] < height)]
+                    lo, hi = sel.quantile(0.02, dim=0), sel.quantile(0.98, dim=0)
+                    boxes.append((float((lo[0] / width).clamp(0, 0.9)), float((hi[0] / width).clamp(0.1, 1.0)),
+                                  float((lo[1] / height).clamp(0, 0.9)), float((hi[1] / height).clamp(0.1, 1.0))))
+                self.set_rois(boxes)
+                obs = []
+                for g_ in range(groups):
+                    dino, depth, _ = self.render_roi(moved.to(dev), g_)
+                    obs.append((dino[0], depth[0]))
+                self.set_rois(boxes, obs)
         return self
 
     def render(self, deltas: Tensor):
@@ -184,7 +212,101 @@ class TrackingLoop:
     def set_observation(self, dino: Tensor, depth: Optional[Tensor] = None) -> None:
         self.target = (dino.detach(), None if depth is None else depth.detach())
 
+    # ---- per-object branch -------------------------------------------------------------------------------------
+    @classmethod
+    def crop_box(cls, box, width: int, height: int):
+        """Normalised (xmin, xmax, ymin, ymax) -> pixel box with sides cut to multiples of the DINO patch, and the
+        size it is rendered at (``observation.py:157-172``)."""
+        xmin, xmax, ymin, ymax = box
+        assert 0 <= xmin < xmax <= 1.0 and 0 <= ymin < ymax <= 1.0, "boxes are normalised to the image"
+        x0, x1 = int(xmin * (width - 1)), int(xmax * (width - 1))
+        y0, y1 = int(ymin * (height - 1)), int(ymax * (height - 1))
+        w, h = (x1 - x0) // cls.DINO_PATCH * cls.DINO_PATCH, (y1 - y0) // cls.DINO_PATCH * cls.DINO_PATCH
+        assert w > 0 and h > 0, "a crop must hold at least one 14-pixel patch per side"
+        scale = min(1.0, cls.MAX_ROI_RESOLUTION / max(w, h))
+        # (nerfstudio's rescale_output_resolution floors the new size)
+        return x0, y0, w, h, scale, int(w * scale), int(h * scale)
+
+    def set_rois(self, boxes, observations=None) -> None:
+        """One normalised box per rigid group.  ``observations``: per group (dino [h,w,64], depth [h,w,1] or None) at
+        the crop's render size; None keeps the crops without targets (``render_roi`` works, ``loss`` does not)."""
+        assert len(boxes) == self.part_deltas.shape[0], "one box per rigid group"
+        self.rois = []
+        for g, box in enumerate(boxes):
+            x0, y0, w, h, scale, rw, rh = self.crop_box(box, self.width, self.height)
+            K = self.K.clone()
+            K[:, 0, 2] -= x0          # crop_camera: the principal point moves with the corner
+            K[:, 1, 2] -= y0
+            K[:, :2, :] *= scale      # rescale_output_resolution
+            ids = torch.where(self.labels == g)[0]
+            self.rois.append(dict(K=K, width=rw, height=rh, ids=ids, box=(x0, y0, w, h),
+                                  means=self.means[ids].contiguous(), quats=self.quats[ids].contiguous(),
+                                  scales=self.scales[ids].contiguous(), opacities=self.opacities[ids].contiguous(),
+                                  sh=self.sh[ids].contiguous(), features=self.features[ids].contiguous(),
+                                  labels=self.labels[ids].contiguous(), target=None))
+        if observations is not None:
+            for roi, (dino, depth) in zip(self.rois, observations):
+                roi["target"] = (dino.detach(), None if depth is None else depth.detach())
+
+    def render_roi(self, deltas: Tensor, g: int):
+        """Group ``g`` alone through its crop camera -> (features after the channel MLP [1,h,w,64], expected depth
+        [1,h,w,1], accumulation [1,h,w,1])."""
+        from .rendering import rasterization
+
+        roi = self.rois[g]
+        common = dict(viewmats=self.viewmat, Ks=roi["K"], width=roi["width"], height=roi["height"], packed=False)
+        if self.fused_transform:
+            m, q = roi["means"], roi["quats"]
+            common["rigid"] = (roi["labels"], self.init_p2w, deltas)
+        else:
+            m, q = apply_to_model(self.init_p2w, deltas, roi["labels"], roi["means"], roi["quats"])
+        rgbd, acc, _ = rasterization(m, q, roi["scales"], roi["opacities"], roi["sh"], sh_degree=3, render_mode="RGB+ED",
+                                     tile_size=8, **common)
+        f, fa, _ = rasterization(m, q.detach(), roi["scales"], roi["opacities"], roi["features"], **common)
+        return self.net(f, fa), rgbd[..., 3:4], acc
+
+    @staticmethod
+    def _erode(mask: Tensor, k: int) -> Tensor:
+        """Binary erosion of an [h,w] mask by a k x k box; pixels beyond the border count as set (kornia's default)."""
+        x = mask[None, None].float()
+        return (-torch.nn.functional.max_pool2d(-x, k, stride=1, padding=k // 2))[0, 0] > 0.5
+
+    def _roi_loss(self, use_depth: bool) -> Tensor:
+        real_dino, rend_dino, real_depth, rend_depth, valids = [], [], [], [], []
+        for g in reversed(range(len(self.rois))):
+            roi = self.rois[g]
+            assert roi["target"] is not None, "set_rois(..., observations=...) first"
+            dino, depth, acc = self.render_roi(self.part_deltas, g)
+            t_dino, t_depth = roi["target"]
+            real_dino.append(t_dino.reshape(-1, t_dino.shape[-1]))
+            rend_dino.append(dino.reshape(-1, dino.shape[-1]))
+            if use_depth and t_depth is not None:
+                obs = t_depth.reshape(roi["height"], roi["width"])
+                valid = (acc.reshape(obs.shape) > 0.85) & ~obs.isnan()
+                valid_depths = self._erode(valid, 5)
+                picked = obs[valid_depths]
+                if picked.numel() > 0:          # reject depths far behind the object's median
+                    valid_depths = valid_depths & ~(obs > picked.median() * 1.3)
+                masked = torch.where(valid_depths, obs, torch.zeros_like(obs))
+                nonzero = masked != 0
+                keep = self._erode(valid_depths & nonzero, 9)
+                real_depth.append(torch.where(keep, masked, torch.zeros_like(masked)).reshape(-1))
+                rend_depth.append((depth.reshape(obs.shape) * keep).reshape(-1))
+                valids.append(keep.reshape(-1))
+        loss = (torch.cat(real_dino) - torch.cat(rend_dino)).norm(dim=-1).nanmean()
+        if valids:
+            v = torch.cat(valids)
+            a = torch.clamp(torch.cat(rend_depth) / self.dataset_scale, min=1e-8, max=1.0)[v]
+            b = torch.clamp(torch.cat(real_depth), min=1e-8, max=1.0)[v]
+            pix = (a - b) ** 2
+            pix = pix[pix < self.depth_ignore_threshold ** 2]
+            if pix.numel() > 0:
+                loss = loss + self.depth_loss_mult * pix.mean()
+        return loss
+
     def loss(self, use_depth: bool = True) -> Tensor:
+        if self.rois is not None:
+            return self._roi_loss(use_depth)
         dino, depth, _ = self.render(self.part_deltas)
         loss = (self.target[0] - dino).norm(dim=-1).nanmean()
         if use_depth and self.target[1] is not None:

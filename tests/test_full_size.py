@@ -81,3 +81,44 @@ def test_tracking_loop_reduces_its_loss(gpu):
     assert min(losses[25:]) <= min(losses[:25])
     d = loop.part_deltas.detach()
     assert bool(torch.isfinite(d).all()) and float((d[:, :3].abs().max())) < 0.2
+
+
+def test_tracking_loop_per_object_crops(gpu):
+    """The tracker's per-object branch (rigid_group_optimizer.py:309-364, observation.py:157-174): crop cameras with
+    sides that are multiples of the 14-pixel patch and at most 490 pixels, each group's Gaussians rendered alone
+    through its crop camera -- which must show exactly the window of the full-camera render of that group -- and a
+    frame of iterations on the concatenated crops that brings the loss down."""
+    from pogs_amd import rendering as rd
+    from pogs_amd.tracking import TrackingLoop
+
+    # the box arithmetic of observation.py:157-172 on a camera larger than the limit
+    x0, y0, w, h, scale, rw, rh = TrackingLoop.crop_box((0.1, 0.9, 0.2, 0.8), 1280, 720)
+    assert (x0, y0) == (127, 143) and (w, h) == (1022, 420) and w % 14 == 0 and h % 14 == 0
+    assert scale == 490 / 1022 and (rw, rh) == (490, int(420 * scale))
+
+    loop = TrackingLoop.synthetic(gpu, n=60_000, width=640, height=360, groups=3, seed=1, rois=True)
+    assert sorted(torch.cat([r["ids"] for r in loop.rois]).tolist()) == list(range(60_000))
+    ident = loop.part_deltas.detach()
+    for g, roi in enumerate(loop.rois):
+        x0, y0, w, h = roi["box"]
+        assert w % 14 == 0 and h % 14 == 0 and max(roi["width"], roi["height"]) <= 490
+        assert (roi["width"], roi["height"]) == (w, h)          # no rescale at this size
+        with torch.no_grad():
+            dino, depth, acc = loop.render_roi(ident, g)
+            kw = dict(viewmats=loop.viewmat, Ks=loop.K, width=640, height=360, packed=False,
+                      rigid=(roi["labels"], loop.init_p2w, ident))
+            full, full_acc, _ = rd.rasterization(roi["means"], roi["quats"], roi["scales"], roi["opacities"], roi["sh"],
+                                                 sh_degree=3, render_mode="RGB+ED", tile_size=8, **kw)
+        assert float(full_acc.max()) > 0.9
+        win = (slice(None), slice(y0, y0 + h), slice(x0, x0 + w))
+        # The same pixels, up to what the tile grid decides: a Gaussian is composited on the tiles its 3-sigma box
+        # touches, an opaque one still has alpha above 1/255 (up to 0.011) beyond that box, and the crop's tile grid
+        # starts at another pixel -- so a pixel here and there gains or loses such a tail (gsplat's semantics too).
+        d_acc = (acc - full_acc[win]).abs()
+        assert float(d_acc.max()) <= 0.012 and float(d_acc.mean()) <= 1e-4 and float((d_acc > 2e-5).float().mean()) < 0.01
+        # (expected depth is accumulated depth / coverage: compared as accumulated depth, which a tail moves by little)
+        d_depth = (depth * acc - full[win][..., 3:4] * full_acc[win]).abs() / float(full[..., 3].max())
+        assert float(d_depth.max()) <= 0.012 and float(d_depth.mean()) <= 1e-4
+    losses = loop.frame(30)
+    assert len(losses) == 30 and all(l == l for l in losses)
+    assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
