@@ -190,16 +190,69 @@ def tracking_config(args, dev):
     ms_two_step, _ = timed()
     loop.fused_transform = True         # default: the transform inside the projection kernels
     ms, losses = timed()
+
+    # every entry point's share of an iteration (HIP events, separate pass), and the dominant compositor launch
+    full = rendering.StageTimer()
+    rendering.set_stage_timer(full)
+    loop.frame(iters)
+    torch.cuda.synchronize()
+    rendering.set_stage_timer(None)
+    stages = {k: v[1] / iters for k, v in full.summary().items()}            # ms per iteration, both renders together
+    with torch.no_grad():
+        common = dict(viewmats=loop.viewmat, Ks=loop.K, width=loop.width, height=loop.height, packed=False,
+                      rigid=(loop.labels, loop.init_p2w, loop.part_deltas.detach()))
+        timer = rendering.StageTimer(only=("pr_raster_fwd",))
+        rendering.set_stage_timer(timer)
+        for _ in range(10):
+            _, _, meta = rendering.rasterization(loop.means, loop.quats, loop.scales, loop.opacities, loop.features,
+                                                 **common)
+        torch.cuda.synchronize()
+        rendering.set_stage_timer(None)
+    n_calls, t_ms = timer.summary()["pr_raster_fwd"]
+    I, P, D = meta["n_composited_isects"], loop.width * loop.height, 64
+    dom_bytes = I * (28 + 4 * D) + P * (4 * D + 8)
+    avg_ms = t_ms / n_calls
+    achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
+
+    # the per-object branch (the reference tracker's default): one crop camera and Gaussian subset per rigid group
+    roi_loop = TrackingLoop.synthetic(dev, n=200_000, width=640, height=360, groups=4, seed=0, rois=True)
+    for _ in range(max(args.warmup, 1)):
+        roi_loop.frame(iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        roi_loop.frame(iters)
+    torch.cuda.synchronize()
+    ms_roi = (time.perf_counter() - t0) / args.steps * 1e3
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        from pogs_amd.scenes import make_scene
+        sc = make_scene(200_000, 640, 360, n_features=64, seed=0)
+        port = cpu_baseline(sc, 64, 16, target_s=15.0)
+        per_iter_ms = P / (port["value"] * 1e6) * 1e3
+        cpu = {"value": per_iter_ms * iters, "unit": "ms/frame", "cores": port["cores"], "kind": "port",
+               "sample": "50 x one fused RGB+ED+64-feature render forward+backward of the same scene by the oracle "
+                         "(stands for an iteration's two renders; MLP, losses, pose update not included): "
+                         + port["sample"]}
     return {
         "metric": "ms/frame tracking (200k Gauss, 640x360, 50 iters)", "value": ms, "unit": "ms/frame", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False,
         "scaling": "replicas only", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "tracking loop: per iteration rigid-group transform, RGB+ED render at tile 8, 64-channel "
-                               "feature render at tile 16 + channel MLP, L2 losses, backward to [G,7] pose deltas, Adam",
+                               "feature render at tile 16 (depth order shared) + channel MLP, fused loss, backward to "
+                               "[G,7] pose deltas, Adam",
                    "gaussians": 200_000, "width": 640, "height": 360, "iterations_per_frame": iters, "groups": 4,
                    "loss_first_to_last": [losses[0], losses[-1]],
-                   "transform": "inside the projection kernels", "ms_per_frame_transform_as_own_pass": ms_two_step},
-        "roofline": None, "cpu_baseline": None,
+                   "transform": "inside the projection kernels", "ms_per_frame_transform_as_own_pass": ms_two_step,
+                   "ms_per_frame_per_object_crops": ms_roi,
+                   "crop_sizes": [(r["width"], r["height"], int(r["ids"].numel())) for r in roi_loop.rois],
+                   "stages_ms_per_iteration": {k: round(v, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}},
+        "roofline": {"bound": "hbm", "kernel": "pr_raster_fwd of the 64-channel feature render", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms, "n_isects_composited": I,
+                     "limited_by": "920 tiles: the launch is a few long dependent chains per SIMD, not bandwidth"},
+        "cpu_baseline": cpu,
     }
 
 

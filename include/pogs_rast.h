@@ -235,6 +235,23 @@ int pr_raster_fwd_plan(int D, int tile_size, int64_t n_tiles_total, int *pixels_
 int pr_raster_bwd_plan(int D, int tile_size, int64_t n_tiles_total, int geom_grad, int color_grad,
                        int *pixels_per_lane, int *channels_per_pass, int *matrix_cores);
 
+/* ---- the tracker's per-iteration loss (value and gradients in one kernel each) ----
+ * Replaces the element-wise / reduction chain of get_optim_loss (pogs/tracking/rigid_group_optimizer.py:364, 373-386):
+ *   loss = nanmean_p ||target[p,:] - rendered[p,:]||_2
+ *        + mult * mean over kept p of (clamp(depth[p] * inv_scale, 1e-8, 1) - clamp(target_depth[p], 1e-8, 1))^2
+ * rendered, target [P,D] (D a multiple of 4, rows 16-byte aligned); depth, target_depth [P] or both NULL (no depth
+ * term); valid [P] bytes or NULL (all): pixels that may enter the depth term; kept = valid and squared error < cut2.
+ * sums[4] (device, written here): sum of finite norms, their number, sum of kept squared errors, their number;
+ * loss[1] (device).  Without a kept pixel the depth term is left out, as the reference leaves out a NaN mean. */
+int pr_track_loss_fwd(int64_t P, int D, const float *rendered, const float *target, const float *depth,
+                      const float *target_depth, const uint8_t *valid, float inv_scale, float cut2, float mult,
+                      float *sums, float *loss, void *stream);
+/* Gradients for the cotangent v_loss[1] (device) of the loss: v_rendered[P,D] and, unless NULL, v_depth[P], both
+ * overwritten.  sums as pr_track_loss_fwd left it. */
+int pr_track_loss_bwd(int64_t P, int D, const float *rendered, const float *target, const float *depth,
+                      const float *target_depth, const uint8_t *valid, float inv_scale, float cut2, float mult,
+                      const float *sums, const float *v_loss, float *v_rendered, float *v_depth, void *stream);
+
 /* ---- rigid-group transform of the Gaussian model (the tracker's per-iteration pose update) ----
  * Replaces the Warp kernel apply_to_model (pogs/tracking/utils.py:53-93, launched at
  * pogs/tracking/rigid_group_optimizer.py:466-477) and its wp.Tape backward (:413-430).

@@ -74,6 +74,8 @@ SIGNATURES = {
                                      c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "pr_project_bwd_rigid": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float, _P, _P,
                                      c_int, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "pr_track_loss_fwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]),
+    "pr_track_loss_bwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P, _P]),
     "pr_rigid_fwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pr_rigid_bwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

@@ -920,7 +920,7 @@ def rasterization(
     backgrounds: Optional[Tensor] = None, render_mode: str = "RGB", sparse_grad: bool = False,
     absgrad: bool = False, rasterize_mode: str = "classic", channel_chunk: int = 32, distributed: bool = False,
     camera_model: str = "pinhole", covars: Optional[Tensor] = None, features: Optional[Tensor] = None,
-    rigid: Optional[Tuple[Tensor, Tensor, Tensor]] = None,
+    rigid: Optional[Tuple[Tensor, Tensor, Tensor]] = None, depth_order=None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize N 3-D Gaussians to C images; gsplat 1.4.0 ``rasterization`` signature.
 
@@ -933,6 +933,12 @@ def rasterization(
     init_p2ws [G,7], p_deltas [G,7])``: the model is frozen and every Gaussian is moved by its group's
     ``p2w * delta * inverse(p2w)`` inside the projection kernels (the tracker's ``apply_to_model`` without its pass
     over the model, forward or backward); gradients reach ``p_deltas`` and the view matrices only.
+    ``depth_order``: ``meta["depth_order"]`` of an earlier call on the SAME Gaussian positions, shapes and cameras
+    (view matrices, intrinsics, image size, clipping planes: everything the projection's culling depends on -- a
+    culled Gaussian is sorted with depth 0, as gsplat reports it).  The tracker renders the model twice per
+    iteration through one camera, colours at tile 8 and features at tile 16: tile size, channels and appearance do
+    not enter the front-to-back order, so the second call skips its depth sort.  The caller vouches for the
+    sameness; nothing checks it.
     """
     N = means.shape[0]
     C = viewmats.shape[0]
@@ -981,7 +987,10 @@ def rasterization(
             means.detach(), quats.detach(), scales.detach(), labels, init_p2ws, p_deltas, viewmats, Ks, width, height,
             float(eps2d), float(near_plane), float(far_plane), float(radius_clip), rasterize_mode == "antialiased")
     # the two-level device sort runs its depth level on a second stream for large models
-    depth_order = _depth_order_async(depths) if (not _TILE_LISTS and C * N >= _ASYNC_DEPTH_ORDER_MIN) else None
+    if depth_order is not None:
+        assert not _TILE_LISTS and depth_order[0].shape == (C * N,) and depth_order[0].device == depths.device
+    else:
+        depth_order = _depth_order_async(depths) if (not _TILE_LISTS and C * N >= _ASYNC_DEPTH_ORDER_MIN) else None
     opac = opacities[None, :].expand(C, N)
     if compensations is not None:
         opac = opac * compensations
@@ -1049,6 +1058,6 @@ def rasterization(
         "camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d, "depths": depths,
         "conics": conics, "opacities": opac, "tile_width": tile_width, "tile_height": tile_height,
         "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
-        "n_composited_isects": flatten_ids.numel(),
+        "n_composited_isects": flatten_ids.numel(), "depth_order": depth_order,
     }, _ReferenceBinning(means2d, radii, depths, tile_size, tile_width, tile_height))
     return render_colors, render_alphas, meta

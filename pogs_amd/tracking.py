@@ -82,6 +82,62 @@ def apply_to_model(init_p2ws: Tensor, p_deltas: Tensor, group_labels: Tensor, me
     return _ApplyToModel.apply(init_p2ws, p_deltas, group_labels, means, quats, quats_grad)
 
 
+class _TrackLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rendered, target, depth, target_depth, valid, inv_scale, cut2, mult):
+        _lib.load()
+        D = rendered.shape[-1]
+        rendered, target = rendered.contiguous().view(-1, D), target.contiguous().view(-1, D)
+        P = rendered.shape[0]
+        assert target.shape == rendered.shape and rendered.dtype == target.dtype == torch.float32
+        if depth is not None:
+            depth, target_depth = depth.contiguous().view(-1), target_depth.contiguous().view(-1)
+            assert depth.shape == target_depth.shape == (P,)
+        if valid is not None:
+            valid = valid.contiguous().view(-1)
+            assert valid.dtype == torch.bool and valid.shape == (P,)
+        sums = torch.empty(4, dtype=torch.float32, device=rendered.device)
+        loss = torch.empty((), dtype=torch.float32, device=rendered.device)
+        with torch.cuda.device(rendered.device):
+            _call("pr_track_loss_fwd", P, D, _ptr(rendered), _ptr(target), _ptr(depth), _ptr(target_depth), _ptr(valid),
+                  inv_scale, cut2, mult, _ptr(sums), _ptr(loss), _stream())
+        ctx.save_for_backward(rendered, target, depth, target_depth, valid, sums)
+        ctx.consts = (inv_scale, cut2, mult)
+        return loss
+
+    @staticmethod
+    def backward(ctx, v_loss):
+        rendered, target, depth, target_depth, valid, sums = ctx.saved_tensors
+        inv_scale, cut2, mult = ctx.consts
+        P, D = rendered.shape
+        v_rendered = torch.empty_like(rendered)
+        v_depth = torch.empty_like(depth) if depth is not None and ctx.needs_input_grad[2] else None
+        v_loss = v_loss.contiguous().float()
+        with torch.cuda.device(rendered.device):
+            _call("pr_track_loss_bwd", P, D, _ptr(rendered), _ptr(target), _ptr(depth), _ptr(target_depth), _ptr(valid),
+                  inv_scale, cut2, mult, _ptr(sums), _ptr(v_loss), _ptr(v_rendered), _ptr(v_depth), _stream())
+        return v_rendered, None, v_depth, None, None, None, None, None
+
+
+def tracking_loss(rendered: Tensor, target: Tensor, depth: Optional[Tensor] = None, target_depth: Optional[Tensor] = None,
+                  valid: Optional[Tensor] = None, dataset_scale: float = 1.0, depth_ignore_threshold: float = 0.26,
+                  depth_loss_mult: float = 3.7) -> Tensor:
+    """The tracker's loss (``rigid_group_optimizer.py:364, 373-386``) in one kernel, with one more for its gradients:
+    ``(target - rendered).norm(dim=-1).nanmean()`` over the [..., D] features plus, when depths are given,
+    ``depth_loss_mult`` times the mean over the kept pixels of ``(clamp(depth / dataset_scale, 1e-8, 1) -
+    clamp(target_depth, 1e-8, 1)) ** 2`` -- kept: ``valid`` (bool, default all) and squared error below
+    ``depth_ignore_threshold ** 2``.  Gradients reach ``rendered`` and ``depth``.  The returned tensor keeps the
+    shapes given: the gradient of ``rendered`` comes back in its own shape."""
+    shape, dshape = rendered.shape, None if depth is None else depth.shape
+    out = _TrackLoss.apply(rendered.reshape(-1, shape[-1]), target.reshape(-1, shape[-1]),
+                           None if depth is None else depth.reshape(-1),
+                           None if target_depth is None else target_depth.reshape(-1),
+                           None if valid is None else valid.reshape(-1), 1.0 / dataset_scale,
+                           depth_ignore_threshold ** 2, depth_loss_mult)
+    del dshape
+    return out
+
+
 def identity_7vec(device="cuda") -> Tensor:
     """The identity pose as a [1,7] row (pogs/tracking/utils.py:95-99)."""
     return torch.tensor([[0, 0, 0, 1, 0, 0, 0]], dtype=torch.float32, device=device)
@@ -204,9 +260,11 @@ class TrackingLoop:
             common["rigid"] = (self.labels, self.init_p2w, deltas)
         else:
             m, q = apply_to_model(self.init_p2w, deltas, self.labels, self.means, self.quats)
-        rgbd, _, _ = rasterization(m, q, self.scales, self.opacities, self.sh, sh_degree=3, render_mode="RGB+ED",
-                                   tile_size=8, **common)
-        f, fa, _ = rasterization(m, q.detach(), self.scales, self.opacities, self.features, **common)
+        rgbd, _, meta = rasterization(m, q, self.scales, self.opacities, self.sh, sh_degree=3, render_mode="RGB+ED",
+                                      tile_size=8, **common)
+        # same positions, same camera: the feature render reuses the first render's depth order
+        f, fa, _ = rasterization(m, q.detach(), self.scales, self.opacities, self.features,
+                                 depth_order=meta["depth_order"], **common)
         return self.net(f, fa), rgbd[..., 3:4], rgbd[..., :3]
 
     def set_observation(self, dino: Tensor, depth: Optional[Tensor] = None) -> None:
@@ -260,9 +318,10 @@ class TrackingLoop:
             common["rigid"] = (roi["labels"], self.init_p2w, deltas)
         else:
             m, q = apply_to_model(self.init_p2w, deltas, roi["labels"], roi["means"], roi["quats"])
-        rgbd, acc, _ = rasterization(m, q, roi["scales"], roi["opacities"], roi["sh"], sh_degree=3, render_mode="RGB+ED",
-                                     tile_size=8, **common)
-        f, fa, _ = rasterization(m, q.detach(), roi["scales"], roi["opacities"], roi["features"], **common)
+        rgbd, acc, meta = rasterization(m, q, roi["scales"], roi["opacities"], roi["sh"], sh_degree=3,
+                                        render_mode="RGB+ED", tile_size=8, **common)
+        f, fa, _ = rasterization(m, q.detach(), roi["scales"], roi["opacities"], roi["features"],
+                                 depth_order=meta["depth_order"], **common)
         return self.net(f, fa), rgbd[..., 3:4], acc
 
     @staticmethod
@@ -291,29 +350,21 @@ class TrackingLoop:
                 nonzero = masked != 0
                 keep = self._erode(valid_depths & nonzero, 9)
                 real_depth.append(torch.where(keep, masked, torch.zeros_like(masked)).reshape(-1))
-                rend_depth.append((depth.reshape(obs.shape) * keep).reshape(-1))
+                rend_depth.append(depth.reshape(-1))
                 valids.append(keep.reshape(-1))
-        loss = (torch.cat(real_dino) - torch.cat(rend_dino)).norm(dim=-1).nanmean()
         if valids:
-            v = torch.cat(valids)
-            a = torch.clamp(torch.cat(rend_depth) / self.dataset_scale, min=1e-8, max=1.0)[v]
-            b = torch.clamp(torch.cat(real_depth), min=1e-8, max=1.0)[v]
-            pix = (a - b) ** 2
-            pix = pix[pix < self.depth_ignore_threshold ** 2]
-            if pix.numel() > 0:
-                loss = loss + self.depth_loss_mult * pix.mean()
-        return loss
+            return tracking_loss(torch.cat(rend_dino), torch.cat(real_dino), torch.cat(rend_depth), torch.cat(real_depth),
+                                 torch.cat(valids), self.dataset_scale, self.depth_ignore_threshold, self.depth_loss_mult)
+        return tracking_loss(torch.cat(rend_dino), torch.cat(real_dino))
 
     def loss(self, use_depth: bool = True) -> Tensor:
         if self.rois is not None:
             return self._roi_loss(use_depth)
         dino, depth, _ = self.render(self.part_deltas)
-        loss = (self.target[0] - dino).norm(dim=-1).nanmean()
         if use_depth and self.target[1] is not None:
-            a = torch.clamp(depth / self.dataset_scale, min=1e-8, max=1.0)
-            b = torch.clamp(self.target[1] / self.dataset_scale, min=1e-8, max=1.0)
-            loss = loss + self.depth_loss_mult * ((a - b) ** 2).mean()
-        return loss
+            return tracking_loss(dino, self.target[0], depth, self.target[1], None, self.dataset_scale,
+                                 self.depth_ignore_threshold, self.depth_loss_mult)
+        return tracking_loss(dino, self.target[0])
 
     def frame(self, niter: int = 50, use_depth: bool = True):
         """One frame's ``niter`` iterations; returns the loss of every iteration (read back once, at the end)."""

@@ -4,9 +4,9 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r3/cfg3_${1:-trace}
 mkdir -p $O
-timeout -k 10 300 python3 bench.py --config cfg3 --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err || { tail $O/bench.err; exit 1; }
+timeout -k 10 300 python3 bench.py --config cfg3 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err || { tail $O/bench.err; exit 1; }
 cat $O/bench.json
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --config cfg3 --steps 1 --warmup 1 > $O/kt.log 2>&1 || { tail $O/kt.log; exit 1; }
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --config cfg3 --steps 1 --warmup 1 --no-cpu-baseline > $O/kt.log 2>&1 || { tail $O/kt.log; exit 1; }
 python3 - $O <<'PY'
 import csv, glob, sys
 o = sys.argv[1]

@@ -524,6 +524,26 @@ def test_raster_forward_block_walks_long_lists(gpu, tuning, shape):
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+def test_depth_order_of_one_call_serves_another(gpu):
+    """rasterization(depth_order=meta["depth_order"]): a second render of the same Gaussians through the same camera
+    -- other tile size, other channels -- must equal the render that sorts for itself."""
+    rd = _rendering()
+    from pogs_amd.scenes import make_scene
+
+    sc = make_scene(150_000, 320, 200, n_features=8, seed=3)
+    a = dict(means=sc.means.to(gpu), quats=sc.quats.to(gpu), scales=sc.log_scales.exp().to(gpu),
+             opacities=torch.sigmoid(sc.opacity_logits).to(gpu), viewmats=sc.viewmats[:1].to(gpu), Ks=sc.Ks[:1].to(gpu),
+             width=320, height=200, packed=False)
+    with torch.no_grad():
+        _, _, meta = rd.rasterization(colors=sc.sh.to(gpu), sh_degree=3, tile_size=8, render_mode="RGB+ED", **a)
+        assert meta["depth_order"] is not None
+        kw = dict(colors=sc.features.to(gpu), tile_size=16, **a)
+        own = rd.rasterization(**kw)
+        shared = rd.rasterization(depth_order=meta["depth_order"], **kw)
+    assert torch.equal(own[0], shared[0]) and torch.equal(own[1], shared[1])
+    assert float(own[1].max()) > 0.9
+
+
 def test_forward_planner_narrows_the_passes_on_small_images(gpu, tuning):
     """Few tiles: the channel passes (rows of one launch) get narrower so that the launch fills the chip; many tiles:
     passes of up to 48 channels at two pixels per lane.  (tiles of the 1080p, 960x540, 640x360 and 450x250 renders)"""
