@@ -214,7 +214,8 @@ def tracking_config(args, dev):
     avg_ms = t_ms / n_calls
     achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
 
-    # the per-object branch (the reference tracker's default): one crop camera and Gaussian subset per rigid group
+    # the per-object branch (the reference tracker's default): one crop camera per rigid group, all crops of a pass in
+    # one render call (rasterization(camera_groups=...)); and as the reference structures it, one call per object
     roi_loop = TrackingLoop.synthetic(dev, n=200_000, width=640, height=360, groups=4, seed=0, rois=True)
     for _ in range(max(args.warmup, 1)):
         roi_loop.frame(iters)
@@ -224,6 +225,14 @@ def tracking_config(args, dev):
         roi_loop.frame(iters)
     torch.cuda.synchronize()
     ms_roi = (time.perf_counter() - t0) / args.steps * 1e3
+    roi_loop.batch_rois = False
+    roi_loop.frame(iters)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(max(args.steps // 4, 1)):
+        roi_loop.frame(iters)
+    torch.cuda.synchronize()
+    ms_roi_loop = (time.perf_counter() - t0) / max(args.steps // 4, 1) * 1e3
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -245,7 +254,7 @@ def tracking_config(args, dev):
                    "gaussians": 200_000, "width": 640, "height": 360, "iterations_per_frame": iters, "groups": 4,
                    "loss_first_to_last": [losses[0], losses[-1]],
                    "transform": "inside the projection kernels", "ms_per_frame_transform_as_own_pass": ms_two_step,
-                   "ms_per_frame_per_object_crops": ms_roi,
+                   "ms_per_frame_per_object_crops": ms_roi, "ms_per_frame_per_object_crops_one_call_per_object": ms_roi_loop,
                    "crop_sizes": [(r["width"], r["height"], int(r["ids"].numel())) for r in roi_loop.rois],
                    "stages_ms_per_iteration": {k: round(v, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}},
         "roofline": {"bound": "hbm", "kernel": "pr_raster_fwd of the 64-channel feature render", "achieved": achieved,

@@ -920,7 +920,7 @@ def rasterization(
     backgrounds: Optional[Tensor] = None, render_mode: str = "RGB", sparse_grad: bool = False,
     absgrad: bool = False, rasterize_mode: str = "classic", channel_chunk: int = 32, distributed: bool = False,
     camera_model: str = "pinhole", covars: Optional[Tensor] = None, features: Optional[Tensor] = None,
-    rigid: Optional[Tuple[Tensor, Tensor, Tensor]] = None, depth_order=None,
+    rigid: Optional[Tuple[Tensor, Tensor, Tensor]] = None, depth_order=None, camera_groups: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize N 3-D Gaussians to C images; gsplat 1.4.0 ``rasterization`` signature.
 
@@ -933,6 +933,9 @@ def rasterization(
     init_p2ws [G,7], p_deltas [G,7])``: the model is frozen and every Gaussian is moved by its group's
     ``p2w * delta * inverse(p2w)`` inside the projection kernels (the tracker's ``apply_to_model`` without its pass
     over the model, forward or backward); gradients reach ``p_deltas`` and the view matrices only.
+    ``camera_groups`` ([C] integer, with ``rigid``): camera c sees only the Gaussians of rigid group
+    ``camera_groups[c]`` -- the tracker's per-object renders (``obj_id`` gather, ``pogs/pogs.py:287-300``, one crop
+    camera per object) as ONE call over C crop cameras of a common image size instead of C calls on C subsets.
     ``depth_order``: ``meta["depth_order"]`` of an earlier call on the SAME Gaussian positions, shapes and cameras
     (view matrices, intrinsics, image size, clipping planes: everything the projection's culling depends on -- a
     culled Gaussian is sorted with depth 0, as gsplat reports it).  The tracker renders the model twice per
@@ -987,6 +990,12 @@ def rasterization(
             means.detach(), quats.detach(), scales.detach(), labels, init_p2ws, p_deltas, viewmats, Ks, width, height,
             float(eps2d), float(near_plane), float(far_plane), float(radius_clip), rasterize_mode == "antialiased")
     # the two-level device sort runs its depth level on a second stream for large models
+    if camera_groups is not None:
+        assert rigid is not None and camera_groups.shape == (C,), "camera_groups goes with rigid=(labels, ...)"
+        # a Gaussian of another group is treated as culled from here on (binning, colours, compositor); the projection's
+        # own backward still visits it and finds zero cotangents
+        radii = torch.where(rigid[0][None, :] == camera_groups.to(rigid[0].dtype)[:, None], radii,
+                            torch.zeros_like(radii))
     if depth_order is not None:
         assert not _TILE_LISTS and depth_order[0].shape == (C * N,) and depth_order[0].device == depths.device
     else:

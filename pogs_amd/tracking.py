@@ -189,6 +189,9 @@ class TrackingLoop:
         self.depth_loss_mult, self.dataset_scale = depth_loss_mult, dataset_scale
         self.depth_ignore_threshold = depth_ignore_threshold
         self.rois = None       # per group: crop camera, Gaussian subset, observation
+        # per-object branch: all crops in one render call per pass (rasterization(camera_groups=...)) instead of one
+        # call per object; False keeps the reference's structure (a loop over objects on gathered subsets)
+        self.batch_rois = True
         # True: the group transform runs inside the projection kernels (rasterization(rigid=...)); False: as its own
         # pass over the model (apply_to_model), the reference's structure.  Same results either way.
         self.fused_transform = fused_transform
@@ -302,6 +305,7 @@ class TrackingLoop:
                                   scales=self.scales[ids].contiguous(), opacities=self.opacities[ids].contiguous(),
                                   sh=self.sh[ids].contiguous(), features=self.features[ids].contiguous(),
                                   labels=self.labels[ids].contiguous(), target=None))
+        self._roi_cams = self._roi_padded = None
         if observations is not None:
             for roi, (dino, depth) in zip(self.rois, observations):
                 roi["target"] = (dino.detach(), None if depth is None else depth.detach())
@@ -330,7 +334,68 @@ class TrackingLoop:
         x = mask[None, None].float()
         return (-torch.nn.functional.max_pool2d(-x, k, stride=1, padding=k // 2))[0, 0] > 0.5
 
+    def render_rois(self, deltas: Tensor):
+        """All groups through their crop cameras in one call per pass: [G,Hm,Wm,*] images at the largest crop size
+        (a crop's own pixels are its top-left [h,w] window; what lies beyond is rendered and ignored)."""
+        from .rendering import rasterization
+
+        G = len(self.rois)
+        Wm, Hm = max(r["width"] for r in self.rois), max(r["height"] for r in self.rois)
+        if getattr(self, "_roi_cams", None) is None:
+            self._roi_cams = (self.viewmat.expand(G, 4, 4).contiguous(), torch.cat([r["K"] for r in self.rois]).contiguous(),
+                              torch.arange(G, dtype=torch.int32, device=self.means.device))
+        viewmats, Ks, groups = self._roi_cams
+        common = dict(viewmats=viewmats, Ks=Ks, width=Wm, height=Hm, packed=False, camera_groups=groups,
+                      rigid=(self.labels, self.init_p2w, deltas))
+        rgbd, acc, meta = rasterization(self.means, self.quats, self.scales, self.opacities, self.sh, sh_degree=3,
+                                        render_mode="RGB+ED", tile_size=8, **common)
+        f, fa, _ = rasterization(self.means, self.quats.detach(), self.scales, self.opacities, self.features,
+                                 depth_order=meta["depth_order"], **common)
+        return self.net(f, fa), rgbd[..., 3:4], acc
+
+    def _roi_targets(self):
+        """Observations of all crops padded to the common size: features NaN beyond a crop (skipped by the mean),
+        depths NaN beyond it (never valid), and the mask of each crop's own pixels."""
+        if getattr(self, "_roi_padded", None) is None:
+            G = len(self.rois)
+            Wm, Hm = max(r["width"] for r in self.rois), max(r["height"] for r in self.rois)
+            dev = self.means.device
+            dino = torch.full((G, Hm, Wm, self.rois[0]["target"][0].shape[-1]), float("nan"), device=dev)
+            depth = torch.full((G, Hm, Wm), float("nan"), device=dev)
+            own = torch.zeros(G, Hm, Wm, dtype=torch.bool, device=dev)
+            has_depth = all(r["target"][1] is not None for r in self.rois)
+            for g, r in enumerate(self.rois):
+                h, w = r["height"], r["width"]
+                dino[g, :h, :w] = r["target"][0].reshape(h, w, -1)
+                own[g, :h, :w] = True
+                if has_depth:
+                    depth[g, :h, :w] = r["target"][1].reshape(h, w)
+            self._roi_padded = (dino, depth if has_depth else None, own)
+        return self._roi_padded
+
+    def _roi_loss_batched(self, use_depth: bool) -> Tensor:
+        t_dino, t_depth, own = self._roi_targets()
+        dino, depth, acc = self.render_rois(self.part_deltas)
+        if not (use_depth and t_depth is not None):
+            return tracking_loss(dino, t_dino)
+        G = own.shape[0]
+        valid = (acc[..., 0] > 0.85) & ~t_depth.isnan()
+        # erosions see the pixels beyond a crop as set, as the crop's own border is seen when it is processed alone
+        def erode(m, k):
+            x = (m | ~own)[:, None].float()
+            return (-torch.nn.functional.max_pool2d(-x, k, stride=1, padding=k // 2))[:, 0] > 0.5
+        valid_depths = erode(valid, 5) & own
+        med = torch.where(valid_depths, t_depth, torch.full_like(t_depth, float("nan"))).view(G, -1).nanmedian(dim=1).values
+        reject = t_depth > (med * 1.3)[:, None, None]          # (a crop without a valid depth: nan, rejects nothing)
+        valid_depths = valid_depths & ~reject
+        masked = torch.where(valid_depths, t_depth, torch.zeros_like(t_depth))
+        keep = erode(valid_depths & (masked != 0), 9) & own
+        return tracking_loss(dino, t_dino, depth[..., 0], torch.where(keep, masked, torch.zeros_like(masked)), keep,
+                             self.dataset_scale, self.depth_ignore_threshold, self.depth_loss_mult)
+
     def _roi_loss(self, use_depth: bool) -> Tensor:
+        if self.batch_rois:
+            return self._roi_loss_batched(use_depth)
         real_dino, rend_dino, real_depth, rend_depth, valids = [], [], [], [], []
         for g in reversed(range(len(self.rois))):
             roi = self.rois[g]

@@ -119,6 +119,17 @@ def test_tracking_loop_per_object_crops(gpu):
         # (expected depth is accumulated depth / coverage: compared as accumulated depth, which a tail moves by little)
         d_depth = (depth * acc - full[win][..., 3:4] * full_acc[win]).abs() / float(full[..., 3].max())
         assert float(d_depth.max()) <= 0.012 and float(d_depth.mean()) <= 1e-4
+    # all crops in one render call per pass (rasterization(camera_groups=...)) against the loop over objects
+    got = {}
+    for batched in (False, True):
+        loop.batch_rois = batched
+        loop.part_deltas.grad = None
+        loss = loop.loss(use_depth=True)
+        loss.backward()
+        got[batched] = (float(loss), loop.part_deltas.grad.clone())
+    assert abs(got[True][0] - got[False][0]) <= 1e-4 * abs(got[False][0]), (got[True][0], got[False][0])
+    scale = float(got[False][1].abs().max())
+    assert float((got[True][1] - got[False][1]).abs().max()) <= 2e-3 * scale, (got[True][1], got[False][1])
     losses = loop.frame(30)
     assert len(losses) == 30 and all(l == l for l in losses)
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
