@@ -39,7 +39,8 @@ constexpr int WAVE = 64;
 struct Tuning {
   int fwd_ppl;      // POGS_RAST_FWD_PPL: force 1/2/4 pixels per lane in the forward compositor (0 = planner)
   int fwd_chunk;    // POGS_RAST_FWD_CHUNK: widest forward channel pass (0 = planner)
-  int fwd_blocks;   // POGS_RAST_FWD_BLOCKS: 1 = forward compositor with per-4x4-block walks (16x16 tiles), 0 = never, -1 = planner
+  int fwd_blocks;   // POGS_RAST_FWD_BLOCKS: forward compositor with per-4x4-block walks (16x16 tiles): -1 (unset) = planner (small
+                    // images), 0 = never, 1 = ring form everywhere, 2 = batch-by-batch form everywhere
   int fwd_mfma;     // POGS_RAST_FWD_MFMA: 1 = split-bf16 matrix-core colour accumulation for 32..72-channel passes
   int bwd_ppl;      // POGS_RAST_BWD_PPL: as fwd_ppl for the backward compositor
   int bwd_mfma;     // POGS_RAST_BWD_MFMA: -1 (unset) = planner: the float32 matrix-core kernel on 8x8 regions wherever it wins,

@@ -23,7 +23,7 @@ static void read_tuning() {
   g_tuning.fwd_ppl = env_int("POGS_RAST_FWD_PPL", 0);
   g_tuning.fwd_chunk = env_int("POGS_RAST_FWD_CHUNK", 0);
   g_tuning.fwd_mfma = env_int("POGS_RAST_FWD_MFMA", 0);
-  g_tuning.fwd_blocks = env_int("POGS_RAST_FWD_BLOCKS", 0);
+  g_tuning.fwd_blocks = env_int("POGS_RAST_FWD_BLOCKS", -1);
   g_tuning.bwd_ppl = env_int("POGS_RAST_BWD_PPL", 0);
   g_tuning.bwd_mfma = env_int("POGS_RAST_BWD_MFMA", -1);
   g_tuning.mlp_variant = env_int("POGS_MLP_VARIANT", -1);

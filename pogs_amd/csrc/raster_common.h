@@ -214,7 +214,7 @@ int launch_bwd_mm(int cd, int tile_size, bool geom_grad, bool color_grad, bool s
 // raster_fwd_blocks.hip: forward compositor on 16x16 tiles whose wavefronts (one per half tile) walk a list per 4x4
 // pixel block; passes of up to 48 channels, all passes of a call in one launch
 bool fwd_blocks_supports(int cd, int tile_size);
-int launch_fwd_blocks(int cd, int C, int N, int D, int ch_off, int per, int n_pass, const float *means2d,
+int launch_fwd_blocks(int cd, bool ring, int C, int N, int D, int ch_off, int per, int n_pass, const float *means2d,
                       const float *conics, const ColorSegs &cs, const float *opacities, const float *backgrounds, int width,
                       int height, int tile_w, int tile_h, const int32_t *isect_offsets, const int32_t *tile_order,
                       const int32_t *flatten_ids, int64_t n_isects, int ed_channel, float *render_colors,

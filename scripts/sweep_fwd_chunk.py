@@ -19,7 +19,7 @@ for name, n, W, H, ks, D in shapes:
                 opacities=torch.sigmoid(sc.opacity_logits).to(dev), colors=cols, viewmats=sc.viewmats[:1].to(dev), Ks=K.to(dev),
                 width=W, height=H, tile_size=16, packed=False)
     res = []
-    for ppl in (None, 1, 2):
+    for ppl in ((None,) if os.environ.get("POGS_RAST_FWD_BLOCKS") else (None, 1, 2)):
         for chunk in (None, 8, 16, 24, 32, 48):
             if chunk is not None and chunk >= D and chunk != 48:
                 continue

@@ -41,7 +41,7 @@ def run_cases(cases, seed, dev, large=False, only=-1, log=print, oracle_chunk=32
         env = {"POGS_RAST_FWD_PPL": rng.choice(["0", "1", "2", "4"]),
                "POGS_RAST_BWD_PPL": rng.choice(["0", "1", "2", "4"]),
                "POGS_RAST_FWD_MFMA": rng.choice(["0", "1"]), "POGS_RAST_BWD_MFMA": rng.choice(["0", "1", "3", "4", "5", "6", None]),
-               "POGS_RAST_FWD_BLOCKS": rng.choice(["0", "0", "1"]), "POGS_RAST_FWD_CHUNK": rng.choice([None, None, "100", "16"])}
+               "POGS_RAST_FWD_BLOCKS": rng.choice(["0", "0", "1", "2"]), "POGS_RAST_FWD_CHUNK": rng.choice([None, None, "100", "16"])}
         seed_scene = rng.randrange(10**6)
         if only >= 0 and case != only:
             continue

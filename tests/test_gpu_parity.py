@@ -446,7 +446,8 @@ def test_raster_forward_forced_variants(gpu, tuning, ppl, D, mfma):
 
 @pytest.mark.parametrize("D", [3, 4, 19, 36, 48, 65, 97, 100])
 @pytest.mark.parametrize("with_bg", [False, True])
-def test_raster_forward_block_walks(gpu, tuning, D, with_bg):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_raster_forward_block_walks(gpu, tuning, D, with_bg, mode):
     """The forward compositor whose wavefronts walk one list per 4x4 pixel block (POGS_RAST_FWD_BLOCKS=1; passes of up
     to 48 channels, all in one launch): every pixel composites the same Gaussians in the same order with the same
     arithmetic as in the vector kernel at 2 pixels per lane (whose lanes' two pixels also share one dx), so the images
@@ -462,8 +463,8 @@ def test_raster_forward_block_walks(gpu, tuning, D, with_bg):
     tuning(POGS_RAST_FWD_BLOCKS=0, POGS_RAST_FWD_PPL=2, POGS_RAST_FWD_CHUNK=48)
     ref_out, ref_alpha = rd.rasterize_to_pixels(dev["means2d"], dev["conics"], dev["colors"], dev["opacities"], sc.width,
                                                 sc.height, 16, offs, flat, backgrounds=bg, ed_channel=ed)
-    tuning(POGS_RAST_FWD_BLOCKS=1, POGS_RAST_FWD_PPL=None, POGS_RAST_FWD_CHUNK=None)
-    n_pass = (D + 47) // 48
+    tuning(POGS_RAST_FWD_BLOCKS=mode, POGS_RAST_FWD_PPL=None, POGS_RAST_FWD_CHUNK=None)   # 1: ring, 2: batch by batch
+    n_pass = (D + 31) // 32        # a small image: passes of up to 32 channels (48 from 3072 tiles on)
     assert _lib.raster_plan(D, 16, 2 * 5 * 3) == (2, ((D + n_pass - 1) // n_pass + 3) // 4 * 4, False)
     leaves = {k: v.clone().requires_grad_(True) for k, v in dev.items()}
     out, alpha = rd.rasterize_to_pixels(leaves["means2d"], leaves["conics"], leaves["colors"], leaves["opacities"],
@@ -484,7 +485,8 @@ def test_raster_forward_block_walks(gpu, tuning, D, with_bg):
 
 
 @pytest.mark.parametrize("shape", ["many faint Gaussians on one tile", "200k Gaussians at 1024x768"])
-def test_raster_forward_block_walks_long_lists(gpu, tuning, shape):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_raster_forward_block_walks_long_lists(gpu, tuning, shape, mode):
     """Lists far longer than the ring of staged entries (and, in the first scene, more staged entries on one half tile
     than the 16-bit entry numbers of the per-block lists count before they wrap): identical images again, through the
     whole rasterization() call -- the second scene with SH colours, expected depth and features from three tensors."""
@@ -502,7 +504,7 @@ def test_raster_forward_block_walks_long_lists(gpu, tuning, shape):
         flat = torch.arange(n, dtype=torch.int32)
         args = [t.to(gpu) for t in (means2d, conics, colors, opac)]
         outs = []
-        for blocks in (0, 1):
+        for blocks in (0, mode):
             tuning(POGS_RAST_FWD_BLOCKS=blocks, POGS_RAST_FWD_PPL=None if blocks else 2)
             outs.append(rd.rasterize_to_pixels(*args, W, H, 16, offs.to(gpu), flat.to(gpu)))
         assert float(outs[0][1].max()) > 0.5
@@ -511,7 +513,7 @@ def test_raster_forward_block_walks_long_lists(gpu, tuning, shape):
         W, H, F = 1024, 768, 32
         sc = make_scene(200_000, W, H, n_features=F, seed=2)
         outs = []
-        for blocks in (0, 1):
+        for blocks in (0, mode):
             tuning(POGS_RAST_FWD_BLOCKS=blocks, POGS_RAST_FWD_PPL=None if blocks else 2)
             with torch.no_grad():
                 r, a, meta = rd.rasterization(sc.means.to(gpu), sc.quats.to(gpu), sc.log_scales.exp().to(gpu),
@@ -544,14 +546,20 @@ def test_depth_order_of_one_call_serves_another(gpu):
     assert float(own[1].max()) > 0.9
 
 
-def test_forward_planner_narrows_the_passes_on_small_images(gpu, tuning):
-    """Few tiles: the channel passes (rows of one launch) get narrower so that the launch fills the chip; many tiles:
-    passes of up to 48 channels at two pixels per lane.  (tiles of the 1080p, 960x540, 640x360 and 450x250 renders)"""
+def test_forward_planner_on_small_and_large_images(gpu, tuning):
+    """Many tiles: the vector kernel at two pixels per lane, passes of up to 48 channels.  Few tiles and 16 channels or
+    more: the per-block walks (two pixels per lane as well), passes of up to 32 channels; the vector kernel with narrow
+    passes where the block walks are switched off.  (tiles of the 1080p, 960x540, 640x360 and 450x250 renders)"""
     from pogs_amd import _lib
 
     tuning(POGS_RAST_FWD_PPL=None, POGS_RAST_FWD_CHUNK=None, POGS_RAST_FWD_MFMA=None, POGS_RAST_FWD_BLOCKS=None)
     assert _lib.raster_plan(36, 16, 120 * 68) == (2, 36, False)
     assert _lib.raster_plan(100, 16, 120 * 68) == (2, 36, False)
+    assert _lib.raster_plan(96, 16, 60 * 34) == (2, 32, False)
+    assert _lib.raster_plan(64, 16, 40 * 23) == (2, 32, False)
+    assert _lib.raster_plan(64, 16, 29 * 16) == (2, 32, False)
+    assert _lib.raster_plan(8, 16, 29 * 16) == (1, 8, False)
+    tuning(POGS_RAST_FWD_BLOCKS=0)
     assert _lib.raster_plan(96, 16, 60 * 34) == (2, 32, False)
     assert _lib.raster_plan(64, 16, 40 * 23) == (1, 32, False)
     assert _lib.raster_plan(64, 16, 29 * 16) == (1, 16, False)
