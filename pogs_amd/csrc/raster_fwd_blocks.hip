@@ -30,14 +30,17 @@ namespace pr {
 // Ring slots per wavefront.  A slot is 32 bytes of record + a colour row; 64 slots at up to 36 channels are 12 KB
 // (thirteen wavefronts per CU), 32 slots above.
 constexpr int fb_ring(int cd) { return cd <= 36 ? 64 : 32; }
+// List entries tested and staged per batch in the batch form.  (48 or 56 entries, which would let a fourth wavefront
+// per SIMD fit the LDS, were measured 1-3 % slower at 36 channels, with or without the registers held to 128.)
+constexpr int fb_batch(int) { return 64; }
 
 template <int CD, bool RING>
 struct alignas(16) BlockLds {
-  static constexpr int R = RING ? fb_ring(CD) : 64;   // batch mode stages up to 64 entries at a time
+  static constexpr int R = RING ? fb_ring(CD) : fb_batch(CD);   // batch form: list entries per batch
   float4 ra[R];                    // x, y, opacity, A' (= -0.5 a log2e)
   float4 rb[R];                    // B' (= -b log2e), C' (= -0.5 c log2e), list position + 1 (bits), unused
   float col[R * color_row(CD)];
-  unsigned short idx[8][R];        // per block: entry numbers (mod 2^16) of the staged entries that touch it
+  unsigned short idx[8][64];       // per block: entry numbers (mod 2^16) of the staged entries that touch it
 };
 
 // Maximum over the wavefront of a non-negative value that is the same in the eight lanes of a group.
@@ -105,7 +108,8 @@ __global__ void __launch_bounds__(64, CD <= 36 ? 3 : 2) raster_fwd_blocks_kernel
 
   // ---- the list, read two batches ahead (indices of the batch after next; records of the next through the indices
   //      that arrived a batch ago)
-  auto load_ids = [&](int first) { return first + lane < range_hi ? flatten_ids[first + lane] : -1; };
+  constexpr int BS = RING ? 64 : fb_batch(CD);   // list entries per batch of candidates
+  auto load_ids = [&](int first) { return lane < BS && first + lane < range_hi ? flatten_ids[first + lane] : -1; };
   auto load_records = [&](int g) {
     BatchGeometry b;
     b.g = g;
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(64, CD <= 36 ? 3 : 2) raster_fwd_blocks_kernel
   };
   int next = range_lo;  // first list entry of the batch held in `pre`
   BatchGeometry pre = load_records(load_ids(next));
-  int ids_next = load_ids(next + 64);
+  int ids_next = load_ids(next + BS);
   BatchGeometry cur = pre;  // the batch being inserted: lane e holds list entry cur_first + e
   int cur_first = range_lo;
   unsigned long long cand = 0ull;  // its entries that passed the half tile's test and are not staged yet
@@ -266,10 +270,10 @@ __global__ void __launch_bounds__(64, CD <= 36 ? 3 : 2) raster_fwd_blocks_kernel
       if (!alive) k = w;
     }
   } else {
-    for (int first = range_lo; first < range_hi; first += 64) {
+    for (int first = range_lo; first < range_hi; first += BS) {
       cur = pre;
       pre = load_records(ids_next);
-      ids_next = load_ids(first + 128);
+      ids_next = load_ids(first + 2 * BS);
       bool keep = false;
       if (cur.g >= 0) keep = touches_region(cur.xy.x, cur.xy.y, cur.o, cur.ca, cur.cb, cur.cc, rx0, ry0, rx1, ry1);
       cand = __builtin_amdgcn_ballot_w64(keep);
@@ -311,7 +315,7 @@ __global__ void __launch_bounds__(64, CD <= 36 ? 3 : 2) raster_fwd_blocks_kernel
         const int slot = e_now;
         const float4 g = L.ra[slot];
         const float4 h = L.rb[slot];
-        const int e_next = L.idx[q][(it + 1) & (R - 1)];
+        const int e_next = L.idx[q][(it + 1) & 63];
         const int pos1 = __builtin_bit_cast(int, h.z);
         float vis[2];
         bool any = false;
