@@ -365,7 +365,11 @@ class ShardedExchange:
             works.append(dist.all_to_all_single(recv, flat, group=self.group, async_op=True))
             shard = None
         elif self.backend == "nccl":
-            shard = flat[b.lo:b.hi]    # in place: the mean of shard j lands in rank j's own slice of its buffer
+            # the mean of shard j lands in a buffer of rank j's own (RCCL accepts the in-place form, output = input's
+            # own slice, as well; a separate output needs no such assumption and costs 1/G of the bucket)
+            if getattr(b, "shard_grad", None) is None:
+                b.shard_grad = torch.empty(b.shard_len, dtype=flat.dtype, device=flat.device)
+            shard = b.shard_grad
             works.append(dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
         else:
             # no reduce-scatter in this backend: all-reduce the buffer (through the host when it lives on a GPU) and
