@@ -1049,7 +1049,7 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
   if (C < 0 || N < 0 || D <= 0 || width <= 0 || height <= 0 || tile_w <= 0 || tile_h <= 0 || n_isects < 0)
     return PR_EINVAL;
   if (tile_size != 16 && tile_size != 8) return PR_EUNSUPPORTED;
-  if (D > pr_max_channels() || n_isects > 2147483647ll) return PR_EUNSUPPORTED;
+  if (D > pr_max_channels() || n_isects > 2147483647ll - 4096 /* list positions plus a batch of look-ahead stay inside int32 */) return PR_EUNSUPPORTED;
   if ((int64_t)tile_w * tile_size < width || (int64_t)tile_h * tile_size < height) return PR_EINVAL;
   if (C == 0 || n_isects == 0) return PR_OK;
   if (!means2d || !conics || !opacities || !isect_offsets || !flatten_ids || !render_alphas || !last_ids ||
