@@ -49,6 +49,7 @@ struct Tuning {
                     // split-bf16 matrix products at 1 pixel per lane; 3 = deferred split-bf16 colour gradient at 2 pixels
                     // per lane (32/36-channel passes); 4 = colour gradients in a split-bf16 kernel of their own (up to 48
                     // channels); 5 = the float32 matrix-core kernel for every call it is built for
+  int bwd_window;   // POGS_RAST_BWD_WINDOW: widest channel window (16/32/48) of the colour-gradient launches (0 = planner)
   int mlp_variant;  // POGS_MLP_VARIANT: -1 = default
   int depth_sort;   // POGS_RAST_DEPTH_SORT: 0 = chained-scan radix sort (onesweep.h), 1 = rocPRIM's radix sort for both binning
                     // sorts, 2 = sample sort of the depth keys between 32 K and 1.25 M Gaussians

@@ -26,6 +26,7 @@ static void read_tuning() {
   g_tuning.fwd_blocks = env_int("POGS_RAST_FWD_BLOCKS", -1);
   g_tuning.bwd_ppl = env_int("POGS_RAST_BWD_PPL", 0);
   g_tuning.bwd_mfma = env_int("POGS_RAST_BWD_MFMA", -1);
+  g_tuning.bwd_window = env_int("POGS_RAST_BWD_WINDOW", 0);
   g_tuning.mlp_variant = env_int("POGS_MLP_VARIANT", -1);
   g_tuning.depth_sort = env_int("POGS_RAST_DEPTH_SORT", 0);
 }

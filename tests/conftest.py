@@ -21,7 +21,7 @@ def gpu():
     return torch.device("cuda:0")
 
 
-_TUNING_VARS = ("POGS_RAST_FWD_BLOCKS", "POGS_RAST_FWD_PPL", "POGS_RAST_FWD_CHUNK", "POGS_RAST_FWD_MFMA", "POGS_RAST_BWD_PPL",
+_TUNING_VARS = ("POGS_RAST_BWD_WINDOW", "POGS_RAST_FWD_BLOCKS", "POGS_RAST_FWD_PPL", "POGS_RAST_FWD_CHUNK", "POGS_RAST_FWD_MFMA", "POGS_RAST_BWD_PPL",
                 "POGS_RAST_BWD_MFMA", "POGS_MLP_VARIANT", "POGS_RAST_DEPTH_SORT", "POGS_RAST_BWD_SPLIT")
 
 
