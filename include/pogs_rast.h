@@ -87,6 +87,12 @@ int pr_sh_bwd(int C, int N, int K, int degree, const float *means, const float *
  * (closed form -R^T t), and the cotangent of viewmats [C,4,4] (overwritten) as the derivative of the general matrix
  * inverse gives it -- what gsplat's `rasterization` obtains from `torch.inverse(viewmats)` when it forms the SH view
  * directions. */
+/* Camera-space depth of EVERY Gaussian, culled or not: depths[c,n] = (viewmats[c] * means[n]).z, bit-identical to what
+ * pr_project_fwd writes for the Gaussians it keeps (it writes 0 for the ones it culls, as gsplat reports them).  A
+ * depth order built from these (pr_depth_order) depends on positions and view matrices alone, so one order serves
+ * every render of the same model through the same view matrix, whatever its intrinsics, image size or channels (POGS
+ * renders three per training iteration, pogs/pogs.py:352,419,493).  No counterpart in gsplat. */
+int pr_view_depths(int C, int N, const float *means, const float *viewmats, float *depths, void *stream);
 int pr_campos_fwd(int C, const float *viewmats, float *campos, void *stream);
 int pr_campos_bwd(int C, const float *viewmats, const float *v_campos, float *v_viewmats, void *stream);
 

@@ -29,6 +29,7 @@ SIGNATURES = {
                                _P, _P, _P, _P, _P, _P]),
     "pr_sh_fwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P]),
     "pr_sh_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, _P, _P, _P]),
+    "pr_view_depths": (c_int, [c_int, c_int, _P, _P, _P, _P]),
     "pr_campos_fwd": (c_int, [c_int, _P, _P, _P]),
     "pr_campos_bwd": (c_int, [c_int, _P, _P, _P, _P]),
     "pr_isect_count_scratch_bytes": (c_size_t, [c_int, c_int]),

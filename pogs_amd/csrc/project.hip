@@ -43,6 +43,12 @@ __device__ __forceinline__ Cam load_cam(const float *__restrict__ viewmats, cons
   return cam;
 }
 
+// Camera-space depth of a point, with the order of operations pinned: the projection and pr_view_depths must produce
+// the same bits (the depth order built from one is used with the other's visibility).
+__device__ __forceinline__ float view_depth(float r20, float r21, float r22, float t2, float x, float y, float z) {
+  return __builtin_fmaf(r22, z, __builtin_fmaf(r21, y, r20 * x)) + t2;
+}
+
 // Everything the forward computes per (camera, Gaussian); shared by forward and backward.
 struct Proj {
   float tx, ty, tz;          // camera-space mean
@@ -100,7 +106,7 @@ __device__ __forceinline__ bool project_one(const Cam &cam, const float *p, int 
                                             float near_plane, float far_plane, Proj &P) {
   P.tx = cam.R[0] * p[0] + cam.R[1] * p[1] + cam.R[2] * p[2] + cam.t[0];
   P.ty = cam.R[3] * p[0] + cam.R[4] * p[1] + cam.R[5] * p[2] + cam.t[1];
-  P.tz = cam.R[6] * p[0] + cam.R[7] * p[1] + cam.R[8] * p[2] + cam.t[2];
+  P.tz = view_depth(cam.R[6], cam.R[7], cam.R[8], cam.t[2], p[0], p[1], p[2]);
   if (!(P.tz > near_plane && P.tz < far_plane)) return false;
   sym3_congruence(cam.R, P.S, P.Sc);
   float rz = 1.f / P.tz, rz2 = rz * rz;
@@ -822,6 +828,27 @@ __global__ void campos_bwd_kernel(int C, const float *__restrict__ viewmats, con
 }
 }  // namespace
 }  // namespace pr
+
+namespace pr {
+__global__ void __launch_bounds__(256) view_depths_kernel(int C, int N, const float *__restrict__ means,
+                                                          const float *__restrict__ viewmats, float *__restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)C * N) return;
+  const int c = (int)(idx / N), n = (int)(idx % N);
+  const float *V = viewmats + 16 * c;
+  out[idx] = view_depth(V[8], V[9], V[10], V[11], means[3 * n], means[3 * n + 1], means[3 * n + 2]);
+}
+}  // namespace pr
+
+extern "C" int pr_view_depths(int C, int N, const float *means, const float *viewmats, float *depths, void *stream) {
+  if (C < 0 || N < 0) return PR_EINVAL;
+  if (C == 0 || N == 0) return PR_OK;
+  if (!means || !viewmats || !depths) return PR_EINVAL;
+  const int64_t total = (int64_t)C * N;
+  hipLaunchKernelGGL(pr::view_depths_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, C, N,
+                     means, viewmats, depths);
+  return pr::check_launch("pr_view_depths");
+}
 
 extern "C" int pr_campos_fwd(int C, const float *viewmats, float *campos, void *stream) {
   if (C < 0) return PR_EINVAL;

@@ -353,25 +353,40 @@ def set_count_speculation(on: bool) -> None:
     _state.speculate = bool(on)
 
 
-def _depth_order_async(depths: Tensor):
-    """Start the depth sort of all C*N Gaussians on a second stream and return (order, event): it needs the
-    projection's depths only, so it runs next to the colour evaluation and the tile counting instead of in
-    front of the emission (four small radix passes that leave most of the GPU idle when run alone)."""
+def _depth_order_async(depths: Optional[Tensor], means: Optional[Tensor] = None, viewmats: Optional[Tensor] = None):
+    """Start the depth sort of all C*N Gaussians on a second stream and return (order, event): it runs next to the
+    colour evaluation and the tile counting instead of in front of the emission (four small radix passes that leave
+    most of the GPU idle when run alone).  With ``means`` [N,3] and ``viewmats`` [C,4,4] the keys are the camera-space
+    depths of ALL Gaussians (``pr_view_depths``: the projection's own bits for the ones it keeps, where it reports 0
+    for the ones it culls), so the order does not depend on what this call's intrinsics and image size cull and can
+    serve other renders of the same model through the same view matrices, and the sort can start before the projection;
+    else the projection's ``depths`` [C,N]."""
     lib = _lib.load()
-    dev = depths.device
-    C, N = depths.shape
+    if means is not None:
+        means, viewmats = means.detach().contiguous(), viewmats.detach().contiguous()
+        dev, C, N = means.device, viewmats.shape[0], means.shape[0]
+    else:
+        depths = depths.detach().contiguous()
+        dev, (C, N) = depths.device, depths.shape
     main = torch.cuda.current_stream(dev)
     side = _state.side_stream(dev, main)
-    depths = depths.detach().contiguous()
     side.wait_stream(main)
     with torch.cuda.stream(side):
         order = torch.empty(C * N, dtype=torch.int32, device=dev)
         nb = lib.pr_depth_order_scratch_bytes(C, N)
         scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
-        _call("pr_depth_order", C, N, _ptr(depths), _ptr(order), _ptr(scratch), nb, side.cuda_stream)
+        keys = depths
+        if means is not None:
+            keys = torch.empty(C, N, dtype=torch.float32, device=dev)
+            _call("pr_view_depths", C, N, _ptr(means), _ptr(viewmats), _ptr(keys), side.cuda_stream)
+        _call("pr_depth_order", C, N, _ptr(keys), _ptr(order), _ptr(scratch), nb, side.cuda_stream)
         done = torch.cuda.Event()
         done.record(side)
-    depths.record_stream(side)
+    if means is not None:
+        means.record_stream(side)
+        viewmats.record_stream(side)
+    else:
+        depths.record_stream(side)
     order.record_stream(main)
     return order, done
 
@@ -936,12 +951,13 @@ def rasterization(
     ``camera_groups`` ([C] integer, with ``rigid``): camera c sees only the Gaussians of rigid group
     ``camera_groups[c]`` -- the tracker's per-object renders (``obj_id`` gather, ``pogs/pogs.py:287-300``, one crop
     camera per object) as ONE call over C crop cameras of a common image size instead of C calls on C subsets.
-    ``depth_order``: ``meta["depth_order"]`` of an earlier call on the SAME Gaussian positions, shapes and cameras
-    (view matrices, intrinsics, image size, clipping planes: everything the projection's culling depends on -- a
-    culled Gaussian is sorted with depth 0, as gsplat reports it).  The tracker renders the model twice per
-    iteration through one camera, colours at tile 8 and features at tile 16: tile size, channels and appearance do
-    not enter the front-to-back order, so the second call skips its depth sort.  The caller vouches for the
-    sameness; nothing checks it.
+    ``depth_order``: ``meta["depth_order"]`` of an earlier call on the SAME Gaussian positions and view matrices: the
+    front-to-back order of the Gaussians depends on nothing else, so this call skips its depth sort.  An order produced
+    WITHOUT ``rigid`` is built from the depths of all Gaussians, culled or not, and serves renders with any intrinsics,
+    image size, tile size and channels (POGS renders three per training iteration: full-resolution colours, the
+    half-resolution 96 channels, the 450x250 DINO channels); one produced WITH ``rigid`` comes from the projection's
+    depths, where a culled Gaussian counts as depth 0, and serves calls with the same camera and image size only (the
+    tracker's two renders per iteration).  The caller vouches for the sameness; nothing checks it.
     """
     N = means.shape[0]
     C = viewmats.shape[0]
@@ -975,7 +991,10 @@ def rasterization(
     # are waited for on the device, each right before the first kernel that reads it.
     for t in (means, quats, scales, opacities, viewmats, Ks, backgrounds):
         wait_ready(t)
+    sort_async = depth_order is None and not _TILE_LISTS and C * N >= _ASYNC_DEPTH_ORDER_MIN
     if rigid is None:
+        if sort_async:      # keys from the positions and the view matrices alone: the sort starts next to the projection
+            depth_order = _depth_order_async(None, means, viewmats)
         radii, means2d, depths, conics, compensations = fully_fused_projection(
             means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip,
             calc_compensations=(rasterize_mode == "antialiased"))
@@ -998,8 +1017,9 @@ def rasterization(
                             torch.zeros_like(radii))
     if depth_order is not None:
         assert not _TILE_LISTS and depth_order[0].shape == (C * N,) and depth_order[0].device == depths.device
-    else:
-        depth_order = _depth_order_async(depths) if (not _TILE_LISTS and C * N >= _ASYNC_DEPTH_ORDER_MIN) else None
+    elif sort_async:
+        # (with rigid groups the positions are the moved ones, which only the projection knows: its depths then)
+        depth_order = _depth_order_async(depths)
     opac = opacities[None, :].expand(C, N)
     if compensations is not None:
         opac = opac * compensations

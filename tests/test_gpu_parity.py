@@ -546,6 +546,41 @@ def test_depth_order_of_one_call_serves_another(gpu):
     assert float(own[1].max()) > 0.9
 
 
+def test_depth_order_serves_other_intrinsics_and_image_sizes(gpu):
+    """An order produced without rigid groups is sorted on the camera-space depths of ALL Gaussians, so it serves a
+    render through the same view matrix with other intrinsics and another image size (which culls other Gaussians):
+    POGS's half-resolution and 450x250 renders after the full-resolution one.  The keys carry the projection's bits."""
+    rd = _rendering()
+    from pogs_amd import _lib
+    from pogs_amd.scenes import make_scene
+
+    sc = make_scene(150_000, 640, 360, n_features=8, seed=5)
+    a = dict(means=sc.means.to(gpu), quats=sc.quats.to(gpu), scales=sc.log_scales.exp().to(gpu),
+             opacities=torch.sigmoid(sc.opacity_logits).to(gpu), viewmats=sc.viewmats[:1].to(gpu), packed=False)
+    K = sc.Ks[:1].to(gpu)
+    with torch.no_grad():
+        _, _, meta = rd.rasterization(colors=sc.sh.to(gpu), sh_degree=3, Ks=K, width=640, height=360,
+                                      render_mode="RGB+ED", **a)
+        assert meta["depth_order"] is not None
+        for s, (w, h) in ((0.5, (320, 180)), (0.3, (240, 96))):   # the second one also crops the field of view
+            Ks = K.clone()
+            Ks[:, :2] *= s
+            kw = dict(colors=sc.features.to(gpu), Ks=Ks, width=w, height=h, **a)
+            own = rd.rasterization(**kw)
+            shared = rd.rasterization(depth_order=meta["depth_order"], **kw)
+            assert torch.equal(own[0], shared[0]) and torch.equal(own[1], shared[1])
+            assert float(own[1].max()) > 0.9
+        radii, _, depths, _, _ = rd.fully_fused_projection(a["means"], a["quats"], a["scales"], a["viewmats"], K, 640, 360)
+        z = torch.empty_like(depths)
+        lib = _lib.load()
+        assert lib.pr_view_depths(1, sc.means.shape[0], a["means"].data_ptr(), a["viewmats"].data_ptr(), z.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream) == 0
+        torch.cuda.synchronize()
+        seen = (radii > 0).all(-1) if radii.dim() == 3 else radii > 0
+        assert int(seen.sum()) > 10_000 and int((~seen).sum()) > 100
+        assert torch.equal(z[seen], depths[seen])
+
+
 def test_forward_planner_on_small_and_large_images(gpu, tuning):
     """Many tiles: the vector kernel at two pixels per lane, passes of up to 48 channels.  Few tiles and 16 channels or
     more: the per-block walks (two pixels per lane as well), passes of up to 32 channels; the vector kernel with narrow
