@@ -175,9 +175,13 @@ def tracking_config(args, dev):
     loop = TrackingLoop.synthetic(dev, n=200_000, width=640, height=360, groups=4, seed=0)
     iters = 50
 
+    first = []
+
     def timed():
         for _ in range(max(args.warmup, 1)):
-            loop.frame(iters)
+            out = loop.frame(iters)
+            if not first:
+                first.append(out[0])          # the loss before any pose update of this run
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = None
@@ -189,6 +193,9 @@ def tracking_config(args, dev):
     loop.fused_transform = False        # the reference's structure: the transform as its own pass over the model
     ms_two_step, _ = timed()
     loop.fused_transform = True         # default: the transform inside the projection kernels
+    loop.share_binning = False          # tile 8 then tile 16, a binning each (only the depth order shared)
+    ms_two_binnings, _ = timed()
+    loop.share_binning = True           # default: both renders at tile 16 over one binning
     ms, losses = timed()
 
     # every entry point's share of an iteration (HIP events, separate pass), and the dominant compositor launch
@@ -248,12 +255,13 @@ def tracking_config(args, dev):
         "metric": "ms/frame tracking (200k Gauss, 640x360, 50 iters)", "value": ms, "unit": "ms/frame", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False,
         "scaling": "replicas only", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "tracking loop: per iteration rigid-group transform, RGB+ED render at tile 8, 64-channel "
-                               "feature render at tile 16 (depth order shared) + channel MLP, fused loss, backward to "
+        "config": {"workload": "tracking loop: per iteration rigid-group transform, RGB+ED render and 64-channel "
+                               "feature render at tile 16 over one binning + channel MLP, fused loss, backward to "
                                "[G,7] pose deltas, Adam",
                    "gaussians": 200_000, "width": 640, "height": 360, "iterations_per_frame": iters, "groups": 4,
-                   "loss_first_to_last": [losses[0], losses[-1]],
+                   "loss_first_to_last": [first[0], losses[-1]],       # first iteration of the first frame, last of the last
                    "transform": "inside the projection kernels", "ms_per_frame_transform_as_own_pass": ms_two_step,
+                   "ms_per_frame_tile8_then_tile16_a_binning_each": ms_two_binnings,
                    "ms_per_frame_per_object_crops": ms_roi, "ms_per_frame_per_object_crops_one_call_per_object": ms_roi_loop,
                    "crop_sizes": [(r["width"], r["height"], int(r["ids"].numel())) for r in roi_loop.rois],
                    "stages_ms_per_iteration": {k: round(v, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}},

@@ -936,6 +936,7 @@ def rasterization(
     absgrad: bool = False, rasterize_mode: str = "classic", channel_chunk: int = 32, distributed: bool = False,
     camera_model: str = "pinhole", covars: Optional[Tensor] = None, features: Optional[Tensor] = None,
     rigid: Optional[Tuple[Tensor, Tensor, Tensor]] = None, depth_order=None, camera_groups: Optional[Tensor] = None,
+    binning: Optional[Dict] = None,
 ) -> Tuple[Tensor, Tensor, Dict]:
     """Rasterize N 3-D Gaussians to C images; gsplat 1.4.0 ``rasterization`` signature.
 
@@ -958,6 +959,12 @@ def rasterization(
     half-resolution 96 channels, the 450x250 DINO channels); one produced WITH ``rigid`` comes from the projection's
     depths, where a culled Gaussian counts as depth 0, and serves calls with the same camera and image size only (the
     tracker's two renders per iteration).  The caller vouches for the sameness; nothing checks it.
+
+    ``binning``: ``meta["binning"]`` of an earlier call that rendered the SAME Gaussian positions, shapes and opacities
+    through the same cameras at the same image and tile size: this call composites over that call's per-tile lists and
+    runs neither the depth sort nor the tile binning (nor waits for the intersection count).  Channels, appearance,
+    render mode and which inputs carry gradients may differ (the tracker's feature render after its RGB+ED render).
+    Image and tile size are checked, the rest is the caller's promise.
     """
     N = means.shape[0]
     C = viewmats.shape[0]
@@ -991,7 +998,10 @@ def rasterization(
     # are waited for on the device, each right before the first kernel that reads it.
     for t in (means, quats, scales, opacities, viewmats, Ks, backgrounds):
         wait_ready(t)
-    sort_async = depth_order is None and not _TILE_LISTS and C * N >= _ASYNC_DEPTH_ORDER_MIN
+    if binning is not None:
+        assert (binning["tile_size"], binning["width"], binning["height"], binning["n_cameras"]) == (
+            tile_size, width, height, C), "binning= comes from a render of the same cameras, image size and tile size"
+    sort_async = (binning is None and depth_order is None and not _TILE_LISTS and C * N >= _ASYNC_DEPTH_ORDER_MIN)
     if rigid is None:
         if sort_async:      # keys from the positions and the view matrices alone: the sort starts next to the projection
             depth_order = _depth_order_async(None, means, viewmats)
@@ -1058,7 +1068,9 @@ def rasterization(
     tile_height = math.ceil(height / float(tile_size))
     opac = opac.contiguous()
     # compositor lists: only the (Gaussian, tile) pairs that can contribute
-    if depth_order is None and _TILE_LISTS:
+    if binning is not None:
+        flatten_ids, isect_offsets, tile_order = binning["flatten_ids"], binning["isect_offsets"], binning["tile_order"]
+    elif depth_order is None and _TILE_LISTS:
         flatten_ids, isect_offsets, tile_order = _tile_lists(means2d, radii, depths, conics, opac, tile_size,
                                                              tile_width, tile_height)
     else:
@@ -1088,5 +1100,7 @@ def rasterization(
         "conics": conics, "opacities": opac, "tile_width": tile_width, "tile_height": tile_height,
         "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
         "n_composited_isects": flatten_ids.numel(), "depth_order": depth_order,
+        "binning": {"flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "tile_order": tile_order,
+                    "tile_size": tile_size, "width": width, "height": height, "n_cameras": C},
     }, _ReferenceBinning(means2d, radii, depths, tile_size, tile_width, tile_height))
     return render_colors, render_alphas, meta

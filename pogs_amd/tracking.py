@@ -195,6 +195,9 @@ class TrackingLoop:
         # True: the group transform runs inside the projection kernels (rasterization(rigid=...)); False: as its own
         # pass over the model (apply_to_model), the reference's structure.  Same results either way.
         self.fused_transform = fused_transform
+        # True: both renders of an iteration at tile 16, the second over the first one's per-tile lists
+        # (rasterization(binning=...)); False: tile 8 then tile 16 as the reference, sharing the depth order only
+        self.share_binning = True
         # part-to-world poses: identity rotation at each group's centroid (rigid_group_optimizer.py:108-118)
         self.init_p2w = torch.zeros(n_groups, 7, device=dev)
         self.init_p2w[:, 3] = 1.0
@@ -263,11 +266,20 @@ class TrackingLoop:
             common["rigid"] = (self.labels, self.init_p2w, deltas)
         else:
             m, q = apply_to_model(self.init_p2w, deltas, self.labels, self.means, self.quats)
-        rgbd, _, meta = rasterization(m, q, self.scales, self.opacities, self.sh, sh_degree=3, render_mode="RGB+ED",
-                                      tile_size=8, **common)
-        # same positions, same camera: the feature render reuses the first render's depth order
-        f, fa, _ = rasterization(m, q.detach(), self.scales, self.opacities, self.features,
-                                 depth_order=meta["depth_order"], **common)
+        if self.share_binning:
+            # same positions, shapes, opacities, camera and image size: the feature render composites over the per-tile
+            # lists of the RGB+ED render (both at tile 16, where the reference renders the first at 8: the image does
+            # not depend on the tile size beyond the float32 tail of a list)
+            rgbd, _, meta = rasterization(m, q, self.scales, self.opacities, self.sh, sh_degree=3,
+                                          render_mode="RGB+ED", tile_size=16, **common)
+            f, fa, _ = rasterization(m, q.detach(), self.scales, self.opacities, self.features, tile_size=16,
+                                     binning=meta["binning"], **common)
+        else:
+            rgbd, _, meta = rasterization(m, q, self.scales, self.opacities, self.sh, sh_degree=3,
+                                          render_mode="RGB+ED", tile_size=8, **common)
+            # same positions, same camera: the feature render reuses the first render's depth order
+            f, fa, _ = rasterization(m, q.detach(), self.scales, self.opacities, self.features,
+                                     depth_order=meta["depth_order"], **common)
         return self.net(f, fa), rgbd[..., 3:4], rgbd[..., :3]
 
     def set_observation(self, dino: Tensor, depth: Optional[Tensor] = None) -> None:
@@ -348,9 +360,10 @@ class TrackingLoop:
         common = dict(viewmats=viewmats, Ks=Ks, width=Wm, height=Hm, packed=False, camera_groups=groups,
                       rigid=(self.labels, self.init_p2w, deltas))
         rgbd, acc, meta = rasterization(self.means, self.quats, self.scales, self.opacities, self.sh, sh_degree=3,
-                                        render_mode="RGB+ED", tile_size=8, **common)
+                                        render_mode="RGB+ED", tile_size=16 if self.share_binning else 8, **common)
+        shared = dict(binning=meta["binning"]) if self.share_binning else dict(depth_order=meta["depth_order"])
         f, fa, _ = rasterization(self.means, self.quats.detach(), self.scales, self.opacities, self.features,
-                                 depth_order=meta["depth_order"], **common)
+                                 tile_size=16, **shared, **common)
         return self.net(f, fa), rgbd[..., 3:4], acc
 
     def _roi_targets(self):

@@ -121,6 +121,7 @@ def test_tracking_loop_per_object_crops(gpu):
         assert float(d_depth.max()) <= 0.012 and float(d_depth.mean()) <= 1e-4
     # all crops in one render call per pass (rasterization(camera_groups=...)) against the loop over objects
     got = {}
+    loop.share_binning = False            # (tile 8 for the RGB+ED render, as the loop over objects)
     for batched in (False, True):
         loop.batch_rois = batched
         loop.part_deltas.grad = None
@@ -130,6 +131,34 @@ def test_tracking_loop_per_object_crops(gpu):
     assert abs(got[True][0] - got[False][0]) <= 1e-4 * abs(got[False][0]), (got[True][0], got[False][0])
     scale = float(got[False][1].abs().max())
     assert float((got[True][1] - got[False][1]).abs().max()) <= 2e-3 * scale, (got[True][1], got[False][1])
+    # both renders of a pass at tile 16 over one binning: the same loss and pose gradients up to the tails of the lists
+    loop.share_binning = True
+    loop.part_deltas.grad = None
+    loss = loop.loss(use_depth=True)
+    loss.backward()
+    assert abs(float(loss) - got[True][0]) <= 2e-3 * abs(got[True][0]), (float(loss), got[True][0])
+    assert float((loop.part_deltas.grad - got[True][1]).abs().max()) <= 2e-2 * scale, (loop.part_deltas.grad, got[True][1])
     losses = loop.frame(30)
     assert len(losses) == 30 and all(l == l for l in losses)
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
+
+
+def test_tracking_loop_shares_the_binning_of_its_two_renders(gpu):
+    """TrackingLoop.share_binning: RGB+ED and feature render at tile 16 over one set of per-tile lists against tile 8
+    + tile 16 with a binning each (the reference's structure): same loss and pose gradients up to what the tile grid
+    decides about the tails of the lists."""
+    from pogs_amd.tracking import TrackingLoop
+
+    loop = TrackingLoop.synthetic(gpu, n=120_000, width=640, height=360, groups=4, seed=2)
+    with torch.no_grad():       # move the groups off the observation so the gradients are not noise around zero
+        loop.part_deltas[:, :3] += 0.01 * torch.tensor([[1.0, -0.5, 0.3]], device=gpu)
+    got = {}
+    for share in (False, True):
+        loop.share_binning = share
+        loop.part_deltas.grad = None
+        loss = loop.loss(use_depth=True)
+        loss.backward()
+        got[share] = (float(loss), loop.part_deltas.grad.clone())
+    assert got[False][0] > 0 and abs(got[True][0] - got[False][0]) <= 2e-3 * got[False][0], (got[True][0], got[False][0])
+    scale = float(got[False][1].abs().max())
+    assert scale > 0 and float((got[True][1] - got[False][1]).abs().max()) <= 2e-2 * scale, (got[True][1], got[False][1])

@@ -581,6 +581,38 @@ def test_depth_order_serves_other_intrinsics_and_image_sizes(gpu):
         assert torch.equal(z[seen], depths[seen])
 
 
+def test_binning_of_one_call_serves_another(gpu):
+    """rasterization(binning=meta["binning"]): a second render of the same Gaussians through the same cameras at the
+    same image and tile size -- other channels, another render mode, other inputs with gradients -- composites over the
+    first render's per-tile lists and equals, forward and backward, the render that bins for itself."""
+    rd = _rendering()
+    from pogs_amd.scenes import make_scene
+
+    sc = make_scene(150_000, 320, 200, n_features=8, n_views=2, seed=4)
+    a = dict(quats=sc.quats.to(gpu), scales=sc.log_scales.exp().to(gpu), opacities=torch.sigmoid(sc.opacity_logits).to(gpu),
+             viewmats=sc.viewmats.to(gpu), Ks=sc.Ks.to(gpu), width=320, height=200, packed=False, tile_size=16)
+    means = sc.means.to(gpu)
+    with torch.no_grad():
+        _, _, meta = rd.rasterization(means=means, colors=sc.sh.to(gpu), sh_degree=3, render_mode="RGB+ED", **a)
+    assert meta["binning"]["flatten_ids"].numel() == meta["n_composited_isects"] > 0
+    cot = torch.randn(2, 200, 320, 8, device=gpu)
+    got = []
+    for shared in (False, True):
+        m, f = means.clone().requires_grad_(True), sc.features.to(gpu).requires_grad_(True)
+        out, alpha, meta2 = rd.rasterization(means=m, colors=f, binning=meta["binning"] if shared else None, **a)
+        (out * cot).sum().backward()
+        got.append((out.detach(), alpha.detach(), m.grad, f.grad))
+        assert meta2["n_composited_isects"] == meta["n_composited_isects"]
+    for k, (x, y) in enumerate(zip(*got)):
+        if k < 2:
+            assert torch.equal(x, y)
+        else:       # sums of float atomics: the same terms in whatever order the hardware delivers them
+            assert float((x - y).abs().max()) <= 1e-4 * float(x.abs().max()) > 0
+    assert float(got[0][1].max()) > 0.9
+    with pytest.raises(AssertionError):
+        rd.rasterization(means=means, colors=sc.features.to(gpu), binning=meta["binning"], **{**a, "tile_size": 8})
+
+
 def test_forward_planner_on_small_and_large_images(gpu, tuning):
     """Many tiles: the vector kernel at two pixels per lane, passes of up to 48 channels.  Few tiles and 16 channels or
     more: the per-block walks (two pixels per lane as well), passes of up to 32 channels; the vector kernel with narrow
