@@ -428,7 +428,30 @@ def pogs_step_config(args, dev):
     }
 
 
+_RESULT_FD = None
+
+
+def keep_stdout_for_the_result():
+    """Libraries write to file descriptor 1 behind Python's back (RCCL prints a five-line version banner there when
+    its first communicator comes up): from here on descriptor 1 is the error stream, and the one JSON line goes to
+    the original standard output through ``emit``."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line: str) -> None:
+    sys.stdout.flush()
+    data = (line + "\n").encode()
+    fd = 1 if _RESULT_FD is None else _RESULT_FD
+    while data:
+        data = data[os.write(fd, data):]
+
+
 def main():
+    keep_stdout_for_the_result()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -475,15 +498,19 @@ def main():
     if args.config == "cfg3":
         if world != 1:
             raise SystemExit("cfg3 (tracking) is single-GPU in the reference: run replicas, not ranks")
-        print(json.dumps(tracking_config(args, dev)), flush=True)
+        emit(json.dumps(tracking_config(args, dev)))
         return
     if args.config == "pogs_step":
         if world != 1:
             raise SystemExit("pogs_step is measured on one GPU")
-        print(json.dumps(pogs_step_config(args, dev)), flush=True)
+        emit(json.dumps(pogs_step_config(args, dev)))
         return
-    if world > 1:
+    # POGS_BENCH_FORCE_DIST=1: a single rank takes the N > 1 path (process group, barriers, the exchange's library
+    # collectives with one participant) -- a rehearsal of the RCCL calls on a one-GPU box
+    multi = world > 1 or os.environ.get("POGS_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("POGS_BENCH_BACKEND", "nccl")   # "gloo" for a rehearsal on a shared GPU
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -506,7 +533,7 @@ def main():
     # zero_grad(set_to_none=True) semantics, as the reference's trainer does between iterations.
     # --with-optimizer: the same object with one rank (its collectives drop out, the fused Adam runs on everything).
     ex = {"grads": make_exchange(args.exchange, params, lr_scale=args.lr_scale)
-          if world > 1 or args.with_optimizer else None}
+          if multi or args.with_optimizer else None}
     D = 3 + F + 1
     g = torch.Generator().manual_seed(100 + rank)
     v_colors = torch.randn(1, H, W, D, generator=g).to(dev)
@@ -557,7 +584,7 @@ def main():
     t_setup = time.perf_counter()
     n_setup = 0
     # (with more than one rank every step is a collective: the count must not depend on a local clock)
-    fixed = max(n_views, 48) if world > 1 else None
+    fixed = max(n_views, 48) if multi else None
     while (n_setup < fixed) if fixed is not None else (
             n_setup < n_views or (time.perf_counter() - t_setup < args.precondition_s and n_setup < 1000)):
         step()
@@ -573,18 +600,18 @@ def main():
     # about 2 % of the step
     timer = rendering.StageTimer(only=("pr_raster_bwd", "pr_raster_fwd"))
     rendering.set_stage_timer(timer)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     rendering.set_stage_timer(None)
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -602,7 +629,7 @@ def main():
     if grads is not None:
         grads.wait_all()
         torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
 
     if rank == 0:
@@ -675,7 +702,7 @@ def main():
                                     "matrix_cores": fwd_plan[2]},
                             "bwd": {"pixels_per_lane": bwd_plan[0], "channels_per_pass": bwd_plan[1],
                                     "matrix_cores": bwd_plan[2]}},
-                "parallelism": ("camera-sharded dp%d, %s" % (world, grads.describe())) if world > 1 else (
+                "parallelism": ("camera-sharded dp%d, %s" % (world, grads.describe())) if multi else (
                     "single GPU" + (", optimiser step inside the timed region: " + grads.describe()
                                     if grads is not None else "")),
                 "optimizer_in_step": grads is not None, "lr_scale": args.lr_scale if grads is not None else None,
@@ -696,7 +723,7 @@ def main():
             "stages_ms_per_step": {k: round(v, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])},
             "stages_note": "pr_raster_fwd/bwd: HIP events inside the timed region; the others: a separate pass",
         }
-        if world == 1 and not args.no_variants:
+        if not multi and not args.no_variants:
             # the same step with other choices, each timed over the same number of steps after two warm-ups
             variants = {}
 
@@ -736,12 +763,12 @@ def main():
                 torch.cuda.synchronize()
                 ex["grads"] = None
             out["variants"] = variants
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, F, ts)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        emit(json.dumps(out))
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

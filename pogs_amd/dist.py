@@ -46,7 +46,8 @@ class FlatGrads:
 
     def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None, async_op: bool = False):
         """DDP semantics: every rank ends with the mean over ranks of the per-view gradients."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (
+                dist.get_world_size(group) == 1 and not _single_rank_collectives()):
             return None
         if dist.get_backend(group) == "gloo":  # gloo has no AVG
             if self.flat.is_cuda:
@@ -100,7 +101,8 @@ class GradExchange:
         return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=True)
 
     def all_reduce_mean(self, group: Optional[dist.ProcessGroup] = None) -> None:
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (
+                dist.get_world_size(group) == 1 and not _single_rank_collectives()):
             return
         world = dist.get_world_size(group)
         works = []
@@ -252,9 +254,10 @@ class ShardedExchange:
     parameter whose ``.grad`` is None.  A rank sees only its own ``.grad``; learning that every rank had none would
     take one more collective per step.  POGS's groups all receive gradients once their loss terms are active.
 
-    The library reduce-scatter / all-gather of the ``nccl`` backend (RCCL) has executed in no test of this
-    repository: ``direct=False`` on ``gloo`` exercises the same bucket offsets, in-place shard views and mean through
-    an all-reduce that stands in for the reduce-scatter.
+    The library reduce-scatter / all-gather of the ``nccl`` backend (RCCL) has executed with ONE participant only
+    (``POGS_EXCHANGE_SINGLE_RANK_COLLECTIVES=1``, ``tests/test_bench_rehearsal.py``: the calls, streams and buffer
+    shapes, no data between GPUs); ``direct=False`` on ``gloo`` with two ranks exercises the same bucket offsets, shard
+    views and mean through an all-reduce that stands in for the reduce-scatter.
     """
 
     def __init__(self, params: Dict[str, Tensor], update, group: Optional[dist.ProcessGroup] = None,
@@ -267,6 +270,9 @@ class ShardedExchange:
         # sums what it receives; otherwise the library's reduce-scatter (gloo has none: there an all-reduce of the
         # whole buffer stands in for it, so that the non-direct bookkeeping can be run on CPUs).
         self.direct = (self.backend != "nccl") if direct is None else bool(direct)
+        # one rank normally skips the collectives; POGS_EXCHANGE_SINGLE_RANK_COLLECTIVES=1 keeps them (a rehearsal of the
+        # library calls, streams and buffer shapes of the N > 1 path on a one-GPU machine)
+        self.collective = self.world > 1 or _single_rank_collectives()
         self.big_bytes = big_bytes
         self.side = None
         self.hooks = []
@@ -352,7 +358,7 @@ class ShardedExchange:
                     seg.copy_(p.grad.reshape(-1))
         # 2. reduce-scatter (mean): this rank's shard of the summed gradients
         works = []
-        if W == 1:
+        if not self.collective:
             shard = flat[b.lo:b.hi]
         elif self.direct and flat.is_cuda and self.backend == "gloo":
             # rehearsal of the N > 1 path on a shared GPU without RCCL: gloo moves host memory only
@@ -391,17 +397,17 @@ class ShardedExchange:
         with ctx:
             for w in works:
                 w.wait()
-            if W > 1 and self.direct:
+            if self.collective and self.direct:
                 shard = recv.view(W, b.shard_len).sum(dim=0).div_(W)
             segs = [(name, b.flat_param[b.lo + at:b.lo + at + (hi - lo)], shard[at:at + (hi - lo)], lo)
                     for name, lo, hi, at in b.segments()]
             self.update(segs)
             ag = []
-            if W > 1 and cuda and self.backend == "gloo":       # rehearsal: through the host, blocking
+            if self.collective and cuda and self.backend == "gloo":       # rehearsal: through the host, blocking
                 h_full = torch.empty(b.total, dtype=b.flat_param.dtype)
                 dist.all_gather_into_tensor(h_full, b.flat_param[b.lo:b.hi].cpu(), group=self.group)
                 b.flat_param.copy_(h_full)
-            elif W > 1:
+            elif self.collective:
                 ag.append(dist.all_gather_into_tensor(b.flat_param, b.flat_param[b.lo:b.hi], group=self.group,
                                                       async_op=True))
             if cuda:
@@ -413,7 +419,7 @@ class ShardedExchange:
                 # everything the second stream read was allocated on the caller's stream: keep it from being handed
                 # out again there before the second stream is done with it
                 flat.record_stream(self.side)
-                if W > 1 and self.direct:
+                if self.collective and self.direct:
                     recv.record_stream(self.side)
                 if shard is not None:
                     shard.record_stream(self.side)
@@ -421,6 +427,12 @@ class ShardedExchange:
                 ready = _Ready(works=ag)
         for p in b.params:      # one waiter shared by the bucket's parameters (CPU handles can be waited on once)
             p._pogs_ready = ready
+
+
+def _single_rank_collectives() -> bool:
+    import os
+
+    return dist.is_available() and dist.is_initialized() and os.environ.get("POGS_EXCHANGE_SINGLE_RANK_COLLECTIVES") == "1"
 
 
 class _NullContext:
@@ -481,7 +493,7 @@ class ShardAdam:
                     if st is not None:
                         shard[at:at + hi - lo] = st[key]
                 full = torch.empty(b.total, dtype=shard.dtype, device=shard.device)
-                if exchange.world > 1:
+                if exchange.collective:
                     dist.all_gather_into_tensor(full, shard, group=exchange.group)
                 else:
                     full.copy_(shard)
@@ -490,7 +502,7 @@ class ShardAdam:
             for name in b.names:
                 steps = [st["step"] for (n, _, _), st in self.state.items() if n == name]
                 out[name]["step"] = max(steps) if steps else 0
-        if exchange.world > 1:   # a rank that holds no slice of a parameter learns its step count from the others
+        if exchange.collective:   # a rank that holds no slice of a parameter learns its step count from the others
             names = sorted(out)
             t = torch.tensor([out[n]["step"] for n in names], dtype=torch.int64,
                              device=next(iter(exchange.params.values())).device)
@@ -565,5 +577,8 @@ def make_exchange(kind: str, params: Dict[str, Tensor], group=None, lr_scale: fl
         cfg = {k: dict(REFERENCE_ADAM.get(k, {"lr": 1e-3, "eps": 1e-15})) for k in params}
         for c in cfg.values():
             c["lr"] = c["lr"] * lr_scale
-        return ShardedExchange(params, ShardAdam(cfg), group)
+        import os
+
+        direct = os.environ.get("POGS_EXCHANGE_DIRECT")       # "1" / "0" override the backend's default form
+        return ShardedExchange(params, ShardAdam(cfg), group, direct=None if direct is None else direct == "1")
     raise ValueError(kind)
