@@ -195,6 +195,9 @@ def tracking_config(args, dev):
     loop.fused_transform = True         # default: the transform inside the projection kernels
     loop.share_binning = False          # tile 8 then tile 16, a binning each (only the depth order shared)
     ms_two_binnings, _ = timed()
+    loop.fuse_renders = True            # RGB+ED and the features as one 68-channel render
+    ms_fused, _ = timed()
+    loop.fuse_renders = False
     loop.share_binning = True           # default: both renders at tile 16 over one binning
     ms, losses = timed()
 
@@ -262,6 +265,7 @@ def tracking_config(args, dev):
                    "loss_first_to_last": [first[0], losses[-1]],       # first iteration of the first frame, last of the last
                    "transform": "inside the projection kernels", "ms_per_frame_transform_as_own_pass": ms_two_step,
                    "ms_per_frame_tile8_then_tile16_a_binning_each": ms_two_binnings,
+                   "ms_per_frame_one_68_channel_render": ms_fused,
                    "ms_per_frame_per_object_crops": ms_roi, "ms_per_frame_per_object_crops_one_call_per_object": ms_roi_loop,
                    "crop_sizes": [(r["width"], r["height"], int(r["ids"].numel())) for r in roi_loop.rois],
                    "stages_ms_per_iteration": {k: round(v, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}},

@@ -275,6 +275,14 @@ int pr_rigid_bwd(int64_t N, int G, const float *init_p2ws, const float *p_deltas
                  const float *means, const float *quats, const float *v_means_out, const float *v_quats_out,
                  float *v_p_deltas, void *stream);
 
+/* One iteration of the tracker's pose optimiser (pogs/tracking/rigid_group_optimizer.py:432 part_optimizer.step(),
+ * a torch.optim.Adam on the [G,7] deltas, and :411-412, the renormalisation the next iteration opens with):
+ * deltas, grad, exp_avg, exp_avg_sq: [G,7] (x y z qw qx qy qz); step >= 1 is Adam's step count after this update; lr the
+ * scheduled rate of this iteration.  Update as pr_adam_step (no weight decay, no amsgrad); renormalise != 0 then divides
+ * each group's quaternion part by its norm. */
+int pr_pose_step(int G, float *deltas, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t step, double lr,
+                 double beta1, double beta2, double eps, int renormalise, void *stream);
+
 /* The same transform applied INSIDE the projection, for the tracker's loop (frozen model, pose deltas trainable;
  * pogs/tracking/rigid_group_optimizer.py:402-479): pr_project_fwd_rigid is pr_project_fwd on the moved Gaussians
  * without writing them out, except means_world[N,3] (may be NULL) which the view-dependent colours need;

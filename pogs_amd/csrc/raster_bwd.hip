@@ -960,13 +960,15 @@ struct BwdPlan {
 // iteration and the vector kernel's larger regions (half tiles) win: measured at 1M Gaussians, 1080p, 4 channels
 // 0.51 ms against 0.62; at 36 channels 1.19 against 1.02, at 64 channels on a 450x250 image 0.98 against 0.33.  Any
 // other value of the variable, or a forced pixels-per-lane count, keeps the older kernels (tests, A/B runs).
-static bool plan_mm(int D, int tile_size, int geom_grad) {
+static bool plan_mm(int D, int tile_size, int geom_grad, int64_t n_tiles_total) {
   const int cd = pick_chunk(D);
   if (cd < 0 || !bwd_mm_supports(cd, tile_size)) return false;
   const int mode = tuning().bwd_mfma;
   if (mode == 5 || mode == 6) return true;   // 6: as 5 with geometry and colour gradients as separate launches
   if (mode != -1 || tuning().bwd_ppl != 0) return false;
-  return !(tile_size == 16 && cd <= 8 && geom_grad);
+  // (under 3072 tiles the half-tile kernel is a few long walks per SIMD and the 8x8 regions win at any width: the
+  // tracker's RGB+ED backward at 640x360, 920 tiles, 0.196 ms against 0.176)
+  return !(tile_size == 16 && cd <= 8 && geom_grad && n_tiles_total >= 3072);
 }
 
 // Geometry gradients need the dot product over ALL channels in one pass; colour-only gradients can be
@@ -1010,7 +1012,7 @@ extern "C" int pr_raster_bwd_plan(int D, int tile_size, int64_t n_tiles_total, i
   const BwdPlan plan = plan_bwd(D, geom_grad, color_grad != 0, tile_size, n_tiles_total);
   if (pixels_per_lane) *pixels_per_lane = plan.ppl;
   if (channels_per_pass) *channels_per_pass = plan.per;
-  if (plan_mm(D, tile_size, geom_grad)) {
+  if (plan_mm(D, tile_size, geom_grad, n_tiles_total)) {
     if (pixels_per_lane) *pixels_per_lane = 1;
     if (channels_per_pass) *channels_per_pass = geom_grad ? D : min(D, 48);
     if (matrix_cores) *matrix_cores = 1;
@@ -1102,7 +1104,7 @@ extern "C" int pr_raster_bwd(int C, int N, int D, const float *means2d, const fl
     small_tensors = small_tensors && (int64_t)C * N * cs.ld[i] * 4 < (1ll << 32);
     small_tensors = small_tensors && (int64_t)C * N * gs.ld[i] * 4 < (1ll << 32);
   }
-  if (small_tensors && plan_mm(D, tile_size, geom_grad))
+  if (small_tensors && plan_mm(D, tile_size, geom_grad, (int64_t)C * tile_w * tile_h))
     return launch_bwd_mm(pick_chunk(D), tile_size, geom_grad != 0, any_color_grad, tuning().bwd_mfma == 6, C, N, D, means2d, conics, cs, opacities, backgrounds,
                          width, height, tile_w, tile_h, isect_offsets, tile_order, flatten_ids, n_isects,
                          render_alphas, last_ids, render_colors, ed_channel, v_render_colors, v_render_alphas, absgrad,

@@ -464,7 +464,8 @@ struct FwdPlan {
 };
 
 // The per-block walks, batch by batch, are the planner's choice for small images (under 3072 tiles of 16x16) with 16
-// channels or more: there the lists are long, the Gaussians small against a half tile, and a half tile's wavefront walks
+// channels or more (with 4 channels the vector kernel stays ahead: the tracker's RGB+ED render at 640x360, 0.090 against
+// 0.099 ms): there the lists are long, the Gaussians small against a half tile, and a half tile's wavefront walks
 // a third to a half fewer iterations.  Measured against the vector kernel's best pass width (kernel alone): 200k Gaussians
 // at 640x360 with 64 channels 0.21 -> 0.18 ms; 1M at 450x250 with 64 channels 0.27 -> 0.21; 1M at 960x540 with 96
 // channels 0.51 -> 0.50; at 1080p with 36 channels (8160 tiles) 0.46 against 0.46: no gain, the vector kernel stays.

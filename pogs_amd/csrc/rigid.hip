@@ -60,8 +60,52 @@ rigid_bwd_kernel(int N, int G, const float *__restrict__ init_p2ws, const float 
   flush_groups<BLOCK>(acc, G, v_p_deltas);
 }
 
+// One iteration of the tracker's pose optimiser on the [G,7] deltas: torch.optim.Adam's update (the arithmetic of
+// pr_adam_step, same order of operations), then the division of the quaternion part by its norm with which the
+// reference opens the NEXT iteration (rigid_group_optimizer.py:411-412).  One lane per group.
+__global__ void __launch_bounds__(64)
+pose_step_kernel(int G, float *__restrict__ deltas, const float *__restrict__ grad, float *__restrict__ exp_avg,
+                 float *__restrict__ exp_avg_sq, float step_size, float omb1, float beta2, float omb2, float bias2_sqrt,
+                 float eps, int renormalise) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= G) return;
+  float p[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int i = 7 * g + k;
+    const float gr = grad[i];
+    float m = exp_avg[i], v = exp_avg_sq[i];
+    m = m + (gr - m) * omb1;
+    v = v * beta2 + omb2 * gr * gr;
+    const float denom = sqrtf(v) / bias2_sqrt + eps;
+    p[k] = deltas[i] - step_size * (m / denom);
+    exp_avg[i] = m;
+    exp_avg_sq[i] = v;
+  }
+  if (renormalise) {
+    const float inv = 1.f / sqrtf(p[3] * p[3] + p[4] * p[4] + p[5] * p[5] + p[6] * p[6]);
+#pragma unroll
+    for (int k = 3; k < 7; ++k) p[k] = p[k] * inv;
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) deltas[7 * g + k] = p[k];
+}
+
 }  // namespace
 }  // namespace pr
+
+extern "C" int pr_pose_step(int G, float *deltas, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t step,
+                            double lr, double beta1, double beta2, double eps, int renormalise, void *stream) {
+  if (G < 0 || step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return PR_EINVAL;
+  if (G == 0) return PR_OK;
+  if (!deltas || !grad || !exp_avg || !exp_avg_sq) return PR_EINVAL;
+  // scalars are formed in double and rounded once, as torch does with its Python-float hyperparameters
+  const double bias1 = 1.0 - pow(beta1, (double)step), bias2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(pr::pose_step_kernel, dim3((unsigned)((G + 63) / 64)), dim3(64), 0, (hipStream_t)stream, G, deltas,
+                     grad, exp_avg, exp_avg_sq, (float)(lr / bias1), (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)sqrt(bias2), (float)eps, renormalise);
+  return pr::check_launch("pr_pose_step");
+}
 
 extern "C" int pr_rigid_fwd(int64_t N, int G, const float *init_p2ws, const float *p_deltas, const int32_t *labels,
                             const float *means, const float *quats, float *means_out, float *quats_out,

@@ -198,6 +198,9 @@ class TrackingLoop:
         # True: both renders of an iteration at tile 16, the second over the first one's per-tile lists
         # (rasterization(binning=...)); False: tile 8 then tile 16 as the reference, sharing the depth order only
         self.share_binning = True
+        self.shared_tile = 16       # (8 for both measured the same: 57.5 against 56.7 ms per frame)
+        # True: RGB+ED and the features as ONE render of 68 channels (whole-frame branch)
+        self.fuse_renders = False
         # part-to-world poses: identity rotation at each group's centroid (rigid_group_optimizer.py:108-118)
         self.init_p2w = torch.zeros(n_groups, 7, device=dev)
         self.init_p2w[:, 3] = 1.0
@@ -206,7 +209,11 @@ class TrackingLoop:
         self.part_deltas = torch.zeros(n_groups, 7, device=dev)
         self.part_deltas[:, 3] = 1.0
         self.part_deltas.requires_grad_(True)
-        self.optimizer = torch.optim.Adam([self.part_deltas], lr=pose_lr)
+        # Adam on the deltas (torch.optim.Adam defaults, rigid_group_optimizer.py:93) as one launch per iteration
+        # together with the quaternion renormalisation (pr_pose_step); the state lives as long as the loop, as the
+        # reference's part_optimizer does
+        self.adam = {"step": 0, "exp_avg": torch.zeros_like(self.part_deltas), "betas": (0.9, 0.999), "eps": 1e-8,
+                     "exp_avg_sq": torch.zeros_like(self.part_deltas)}
         self.target = None
 
     @classmethod
@@ -266,14 +273,23 @@ class TrackingLoop:
             common["rigid"] = (self.labels, self.init_p2w, deltas)
         else:
             m, q = apply_to_model(self.init_p2w, deltas, self.labels, self.means, self.quats)
+        if self.fuse_renders:
+            # Both renders differentiate through the means only (the reference's transform hands on quaternions without
+            # gradient, rigid_group_optimizer.py:460-462, and the feature render detaches the rest, pogs/pogs.py:494-497)
+            # and see the same camera: ONE render of [rgb | 64 features | depth] gives the same images and the same
+            # pose gradients (up to what the tile size decides about the float32 tail of a list).
+            out, alpha, _ = rasterization(m, q, self.scales, self.opacities, self.sh, sh_degree=3, render_mode="RGB+ED",
+                                          tile_size=16, features=self.features, **common)
+            F = self.features.shape[1]
+            return self.net(out[..., 3:3 + F], alpha), out[..., 3 + F:], out[..., :3]
         if self.share_binning:
             # same positions, shapes, opacities, camera and image size: the feature render composites over the per-tile
             # lists of the RGB+ED render (both at tile 16, where the reference renders the first at 8: the image does
             # not depend on the tile size beyond the float32 tail of a list)
             rgbd, _, meta = rasterization(m, q, self.scales, self.opacities, self.sh, sh_degree=3,
-                                          render_mode="RGB+ED", tile_size=16, **common)
-            f, fa, _ = rasterization(m, q.detach(), self.scales, self.opacities, self.features, tile_size=16,
-                                     binning=meta["binning"], **common)
+                                          render_mode="RGB+ED", tile_size=self.shared_tile, **common)
+            f, fa, _ = rasterization(m, q.detach(), self.scales, self.opacities, self.features,
+                                     tile_size=self.shared_tile, binning=meta["binning"], **common)
         else:
             rgbd, _, meta = rasterization(m, q, self.scales, self.opacities, self.sh, sh_degree=3,
                                           render_mode="RGB+ED", tile_size=8, **common)
@@ -449,14 +465,30 @@ class TrackingLoop:
         assert self.target is not None, "set_observation first"
         gamma = (self.pose_lr_final / self.pose_lr) ** (1.0 / max(niter, 1))
         losses = []
+        with torch.no_grad():       # "renormalize rotation representation" (:411-412) of the first iteration; the
+            # later ones get theirs from the step before them
+            self.part_deltas[:, 3:] = self.part_deltas[:, 3:] / self.part_deltas[:, 3:].norm(dim=1, keepdim=True)
         for i in range(niter):
-            with torch.no_grad():
-                self.part_deltas[:, 3:] = self.part_deltas[:, 3:] / self.part_deltas[:, 3:].norm(dim=1, keepdim=True)
-            self.optimizer.zero_grad(set_to_none=True)
+            self.part_deltas.grad = None
             loss = self.loss(use_depth)
             loss.backward()
-            self.optimizer.step()
-            self.optimizer.param_groups[0]["lr"] = self.pose_lr * gamma ** (i + 1)
+            # the scheduler's rate of iteration i (ExponentialDecayScheduler, :403-407); the rate is back at pose_lr
+            # when the next frame starts (:441)
+            self.pose_step(self.pose_lr * gamma ** i, renormalise=i + 1 < niter)
             losses.append(loss.detach())
-        self.optimizer.param_groups[0]["lr"] = self.pose_lr      # "reset lr" (:441)
         return torch.stack(losses).tolist()
+
+    @torch.no_grad()
+    def pose_step(self, lr: float, renormalise: bool) -> None:
+        """``part_optimizer.step()`` (:432) and, with ``renormalise``, the renormalisation that opens the next
+        iteration, as one launch."""
+        from .rendering import _call, _ptr
+
+        st, g = self.adam, self.part_deltas.grad
+        if g is None:
+            return                  # torch.optim.Adam skips a parameter without gradient
+        g = g.contiguous()
+        st["step"] += 1
+        _call("pr_pose_step", self.part_deltas.shape[0], _ptr(self.part_deltas), _ptr(g), _ptr(st["exp_avg"]),
+              _ptr(st["exp_avg_sq"]), st["step"], float(lr), st["betas"][0], st["betas"][1], st["eps"],
+              1 if renormalise else 0, torch.cuda.current_stream(g.device).cuda_stream)

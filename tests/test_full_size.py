@@ -153,12 +153,14 @@ def test_tracking_loop_shares_the_binning_of_its_two_renders(gpu):
     with torch.no_grad():       # move the groups off the observation so the gradients are not noise around zero
         loop.part_deltas[:, :3] += 0.01 * torch.tensor([[1.0, -0.5, 0.3]], device=gpu)
     got = {}
-    for share in (False, True):
-        loop.share_binning = share
+    for share in (False, True, "one render"):
+        loop.share_binning, loop.fuse_renders = share is True, share == "one render"
         loop.part_deltas.grad = None
         loss = loop.loss(use_depth=True)
         loss.backward()
         got[share] = (float(loss), loop.part_deltas.grad.clone())
-    assert got[False][0] > 0 and abs(got[True][0] - got[False][0]) <= 2e-3 * got[False][0], (got[True][0], got[False][0])
     scale = float(got[False][1].abs().max())
-    assert scale > 0 and float((got[True][1] - got[False][1]).abs().max()) <= 2e-2 * scale, (got[True][1], got[False][1])
+    assert got[False][0] > 0 and scale > 0
+    for k in (True, "one render"):      # ("one render": RGB+ED and the features as one 68-channel render)
+        assert abs(got[k][0] - got[False][0]) <= 2e-3 * got[False][0], (k, got[k][0], got[False][0])
+        assert float((got[k][1] - got[False][1]).abs().max()) <= 2e-2 * scale, (k, got[k][1], got[False][1])

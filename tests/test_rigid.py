@@ -184,10 +184,51 @@ def test_empty_model_and_full_size_round_trip():
     assert (q0 - dev[4]).abs().max().item() <= 2e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("g", [1, 4, 130])
+def test_pose_step_is_adam_then_the_quaternion_renormalisation(g):
+    """pr_pose_step against what the reference runs per iteration (rigid_group_optimizer.py:409-433): torch.optim.Adam
+    on the [G,7] deltas under the exponentially decaying rate, the quaternion part renormalised before the next loss."""
+    from pogs_amd import _lib
+
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(g)
+    start = torch.randn(g, 7, generator=gen)
+    ref = start.clone().double().requires_grad_(True)       # the reference's sequence in float64
+    opt = torch.optim.Adam([ref], lr=0.004)
+    ours = start.clone().cuda()
+    m, v = torch.zeros_like(ours), torch.zeros_like(ours)
+    niter, gamma = 12, (0.0008 / 0.004) ** (1.0 / 12)
+    stream = torch.cuda.current_stream().cuda_stream
+    with torch.no_grad():
+        ours[:, 3:] = ours[:, 3:] / ours[:, 3:].norm(dim=1, keepdim=True)
+    for i in range(niter):
+        with torch.no_grad():
+            ref[:, 3:] = ref[:, 3:] / ref[:, 3:].norm(dim=1, keepdim=True)
+        grad = torch.randn(g, 7, generator=gen) * (0.5 if i % 3 else 5.0)
+        ref.grad = grad.double()
+        opt.param_groups[0]["lr"] = 0.004 * gamma ** i
+        opt.step()
+        last = i + 1 == niter
+        assert lib.pr_pose_step(g, ours.data_ptr(), grad.cuda().data_ptr(), m.data_ptr(), v.data_ptr(), i + 1,
+                                0.004 * gamma ** i, 0.9, 0.999, 1e-8, 0 if last else 1, stream) == 0
+    torch.cuda.synchronize()
+    assert (ours.double().cpu() - ref.detach()).abs().max().item() <= 2e-6
+    st = opt.state[ref]
+    assert (m.double().cpu() - st["exp_avg"]).abs().max().item() <= 1e-6 * st["exp_avg"].abs().max().item()
+    assert (v.double().cpu() - st["exp_avg_sq"]).abs().max().item() <= 1e-6 * st["exp_avg_sq"].abs().max().item()
+    # the last step leaves the quaternions as Adam left them
+    assert (ours[:, 3:].norm(dim=1) - 1).abs().max().item() > 0
+
+
 def test_rigid_entry_points_validate_arguments_without_a_gpu():
     from pogs_amd import _lib
 
     lib = _lib.load()
+    assert lib.pr_pose_step(-1, None, None, None, None, 1, 0.004, 0.9, 0.999, 1e-8, 1, None) == -1
+    assert lib.pr_pose_step(0, None, None, None, None, 1, 0.004, 0.9, 0.999, 1e-8, 1, None) == 0
+    assert lib.pr_pose_step(4, None, None, None, None, 1, 0.004, 0.9, 0.999, 1e-8, 1, None) == -1   # null pointers
+    assert lib.pr_pose_step(4, None, None, None, None, 0, 0.004, 0.9, 0.999, 1e-8, 1, None) == -1   # step counts from 1
     assert lib.pr_rigid_fwd(-1, 1, None, None, None, None, None, None, None, None) == -1
     assert lib.pr_rigid_fwd(0, 0, None, None, None, None, None, None, None, None) == 0   # nothing to do
     assert lib.pr_rigid_fwd(4, 1, None, None, None, None, None, None, None, None) == -1  # null pointers
