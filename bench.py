@@ -199,6 +199,9 @@ def tracking_config(args, dev):
     ms_fused, _ = timed()
     loop.fuse_renders = False
     loop.share_binning = True           # default: both renders at tile 16 over one binning
+    loop.skip_unused_rgb = True         # the first render as "ED": no loss reads the colours
+    ms_no_rgb, _ = timed()
+    loop.skip_unused_rgb = False
     ms, losses = timed()
 
     # every entry point's share of an iteration (HIP events, separate pass), and the dominant compositor launch
@@ -266,6 +269,7 @@ def tracking_config(args, dev):
                    "transform": "inside the projection kernels", "ms_per_frame_transform_as_own_pass": ms_two_step,
                    "ms_per_frame_tile8_then_tile16_a_binning_each": ms_two_binnings,
                    "ms_per_frame_one_68_channel_render": ms_fused,
+                   "ms_per_frame_first_render_depth_only": ms_no_rgb,
                    "ms_per_frame_per_object_crops": ms_roi, "ms_per_frame_per_object_crops_one_call_per_object": ms_roi_loop,
                    "crop_sizes": [(r["width"], r["height"], int(r["ids"].numel())) for r in roi_loop.rois],
                    "stages_ms_per_iteration": {k: round(v, 4) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}},

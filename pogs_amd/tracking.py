@@ -198,6 +198,7 @@ class TrackingLoop:
         # True: both renders of an iteration at tile 16, the second over the first one's per-tile lists
         # (rasterization(binning=...)); False: tile 8 then tile 16 as the reference, sharing the depth order only
         self.share_binning = True
+        self.skip_unused_rgb = False
         self.shared_tile = 16       # (8 for both measured the same: 57.5 against 56.7 ms per frame)
         # True: RGB+ED and the features as ONE render of 68 channels (whole-frame branch)
         self.fuse_renders = False
@@ -263,8 +264,10 @@ class TrackingLoop:
                 self.set_rois(boxes, obs)
         return self
 
-    def render(self, deltas: Tensor):
-        """-> (features after the channel MLP [1,H,W,64], expected depth [1,H,W,1], rgb [1,H,W,3])."""
+    def render(self, deltas: Tensor, need_rgb: bool = True):
+        """-> (features after the channel MLP [1,H,W,64], expected depth [1,H,W,1], rgb [1,H,W,3]; None when
+        ``need_rgb`` is False and the renders share their binning: the first render is then "ED" instead of
+        "RGB+ED")."""
         from .rendering import rasterization
 
         common = dict(viewmats=self.viewmat, Ks=self.K, width=self.width, height=self.height, packed=False)
@@ -286,8 +289,11 @@ class TrackingLoop:
             # same positions, shapes, opacities, camera and image size: the feature render composites over the per-tile
             # lists of the RGB+ED render (both at tile 16, where the reference renders the first at 8: the image does
             # not depend on the tile size beyond the float32 tail of a list)
+            # (without the colours: expected depth alone -- no view-dependent colours, one composited channel, the same
+            # depth image)
             rgbd, _, meta = rasterization(m, q, self.scales, self.opacities, self.sh, sh_degree=3,
-                                          render_mode="RGB+ED", tile_size=self.shared_tile, **common)
+                                          render_mode="RGB+ED" if need_rgb else "ED", tile_size=self.shared_tile,
+                                          **common)
             f, fa, _ = rasterization(m, q.detach(), self.scales, self.opacities, self.features,
                                      tile_size=self.shared_tile, binning=meta["binning"], **common)
         else:
@@ -296,6 +302,8 @@ class TrackingLoop:
             # same positions, same camera: the feature render reuses the first render's depth order
             f, fa, _ = rasterization(m, q.detach(), self.scales, self.opacities, self.features,
                                      depth_order=meta["depth_order"], **common)
+        if rgbd.shape[-1] == 1:
+            return self.net(f, fa), rgbd, None
         return self.net(f, fa), rgbd[..., 3:4], rgbd[..., :3]
 
     def set_observation(self, dino: Tensor, depth: Optional[Tensor] = None) -> None:
@@ -454,7 +462,9 @@ class TrackingLoop:
     def loss(self, use_depth: bool = True) -> Tensor:
         if self.rois is not None:
             return self._roi_loss(use_depth)
-        dino, depth, _ = self.render(self.part_deltas)
+        # the reference renders the colours whether or not a loss reads them (get_outputs always does); skip_unused_rgb
+        # leaves them out of the optimisation's renders: same loss, same gradients
+        dino, depth, _ = self.render(self.part_deltas, need_rgb=not self.skip_unused_rgb)
         if use_depth and self.target[1] is not None:
             return tracking_loss(dino, self.target[0], depth, self.target[1], None, self.dataset_scale,
                                  self.depth_ignore_threshold, self.depth_loss_mult)

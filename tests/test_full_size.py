@@ -164,3 +164,10 @@ def test_tracking_loop_shares_the_binning_of_its_two_renders(gpu):
     for k in (True, "one render"):      # ("one render": RGB+ED and the features as one 68-channel render)
         assert abs(got[k][0] - got[False][0]) <= 2e-3 * got[False][0], (k, got[k][0], got[False][0])
         assert float((got[k][1] - got[False][1]).abs().max()) <= 2e-2 * scale, (k, got[k][1], got[False][1])
+    # the colours left out of the first render (nothing in the loss reads them): the shared-binning result again
+    loop.share_binning, loop.fuse_renders, loop.skip_unused_rgb = True, False, True
+    loop.part_deltas.grad = None
+    loss = loop.loss(use_depth=True)
+    loss.backward()
+    assert abs(float(loss) - got[True][0]) <= 1e-5 * got[True][0], (float(loss), got[True][0])
+    assert float((loop.part_deltas.grad - got[True][1]).abs().max()) <= 1e-3 * scale, (loop.part_deltas.grad, got[True][1])
