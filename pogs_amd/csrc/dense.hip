@@ -21,6 +21,7 @@
 // Bounds: matrix cores for 256-wide layers (3 x 2 x 256 x 256 flop per row and layer), HBM for the activations
 // that travel between layers (2 x 4 x width bytes per row and layer).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -257,6 +258,129 @@ __global__ void __launch_bounds__(256) dense_wgrad_kernel(int64_t P, int N, int 
     }
 }
 
+// The same contraction with a dW block of NC (128 or 256) rows n and up to 256 columns k per workgroup of NC / 32
+// wavefronts, each owning 64 rows x 16 KT columns (KT x 16 accumulator registers).  The 128 x 64 tiles above re-read G
+// four times and H twice per layer from L2 (3.2 GB at 960x540 rows and 256 x 256: the launch is bound by that traffic);
+// here G is read once and H once per NC rows of dW.  NC = 128: 60 KB of LDS and four wavefronts, so two workgroups
+// share a CU and one loads while the other multiplies.
+template <int NC, int KT>
+__global__ void __launch_bounds__(NC * 2) dense_wgrad_wide_kernel(int64_t P, int N, int K, const float *__restrict__ G,
+                                                                  int ldg, const float *__restrict__ H, int ldh,
+                                                                  float *__restrict__ dW, int ldw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short wide_img[];  // [head | residual][(NC + 32 KT) cols]
+  constexpr int THREADS = NC * 2, KC = 32 * KT, COLS = NC + KC, PLANE = COLS * IMG_PITCH;
+  unsigned short *const img0 = wide_img, *const img1 = wide_img + PLANE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * NC;
+  // loader roles: one column and eight consecutive rows per unit.  G: NC columns x 4 row octets = 2 units per thread;
+  // H: 32 KT columns x 4 octets = HU units per thread
+  const int col = threadIdx.x % NC, oct = threadIdx.x / NC;              // octets {oct, oct + 2}
+  constexpr int HU = 4 * KC / THREADS, HS = 4 / HU;                      // units per thread, octet stride
+  const int col_h = threadIdx.x % KC, oct_h = threadIdx.x / KC;
+  const int64_t steps = (P + 31) / 32;
+  float vg[2][8], vh[HU][8];
+  auto fetch = [&](int64_t step) {
+    const int64_t base = step * 32;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t row = base + 8 * (oct + 2 * u) + i;
+        vg[u][i] = (row < P && n0 + col < N) ? G[row * ldg + n0 + col] : 0.f;
+      }
+#pragma unroll
+    for (int u = 0; u < HU; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t row = base + 8 * (oct_h + HS * u) + i;
+        vh[u][i] = (row < P && col_h < K) ? H[row * ldh + col_h] : 0.f;
+      }
+  };
+  // wavefront (wn, wk): row tiles {2 wn, 2 wn + 1} x column tiles [wk KT/2, (wk + 1) KT/2) -- with a row tile per
+  // wavefront and all columns, every wavefront would read the whole H image
+  constexpr int KH = KT / 2, WN = NC / 64;
+  const int wn = wave % WN, wk = wave / WN;
+  f16v acc[2][KH];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < KH; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+  const int m = lane & 31, kh = lane >> 5;
+  int64_t step = blockIdx.z;
+  if (step < steps) fetch(step);
+  for (; step < steps; step += gridDim.z) {
+    __syncthreads();  // the previous step's operands have been read
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      u4v hi, lo;
+      split8(vg[u], hi, lo);
+      const int at = col * IMG_PITCH + 8 * (oct + 2 * u);
+      *reinterpret_cast<u4v *>(&img0[at]) = hi;
+      *reinterpret_cast<u4v *>(&img1[at]) = lo;
+    }
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      u4v hi, lo;
+      split8(vh[u], hi, lo);
+      const int at = (NC + col_h) * IMG_PITCH + 8 * (oct_h + HS * u);
+      *reinterpret_cast<u4v *>(&img0[at]) = hi;
+      *reinterpret_cast<u4v *>(&img1[at]) = lo;
+    }
+    __syncthreads();
+    if (step + gridDim.z < steps) fetch(step + gridDim.z);  // travels while the matrix cores work
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf8v ah[2], al[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ga = (64 * wn + 32 * i + m) * IMG_PITCH + 16 * s + 8 * kh;
+        ah[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v *>(&img0[ga]));
+        al[i] = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v *>(&img1[ga]));
+      }
+#pragma unroll
+      for (int t = 0; t < KH; ++t) {
+        const int ha = (NC + 32 * (wk * KH + t) + m) * IMG_PITCH + 16 * s + 8 * kh;
+        const bf8v bh = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v *>(&img0[ha]));
+        const bf8v bl = __builtin_bit_cast(bf8v, *reinterpret_cast<const u4v *>(&img1[ha]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][t], 0, 0, 0);
+          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // result tile (i, t): row = n0 + 64 wn + 32 i + (r & 3) + 8 (r >> 2) + 4 kh, column = 32 (wk KH + t) + m
+  settle_mfma_results();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < KH; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 64 * wn + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh, k = 32 * (wk * KH + t) + m;
+        if (n < N && k < K) atomic_add_noret(dW + (int64_t)n * ldw + k, acc[i][t][r]);
+      }
+}
+
+template <int NC, int KT>
+int launch_wgrad_wide(int64_t P, int N, int K, const float *G, int ldg, const float *H, int ldh, float *dW, int ldw,
+                      hipStream_t st) {
+  const int64_t steps = (P + 31) / 32;
+  const unsigned gx = (unsigned)(N / NC);
+  // about one (NC = 256) or two (NC = 128) workgroups per CU, at least four steps each
+  int64_t gz = std::max<int64_t>(1, (NC == 256 ? 256 : 512) / gx);
+  gz = std::min(gz, std::max<int64_t>(1, steps / 4));
+  const size_t lds = (size_t)2 * (NC + 32 * KT) * IMG_PITCH * sizeof(unsigned short);
+  PR_HIP(hipFuncSetAttribute((const void *)dense_wgrad_wide_kernel<NC, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((dense_wgrad_wide_kernel<NC, KT>), dim3(gx, 1, (unsigned)gz), dim3(NC * 2), lds, st, P, N, K, G, ldg,
+                     H, ldh, dW, ldw);
+  return check_launch("pr_dense_wgrad");
+}
+
 // One wavefront per row: out = y / (|y| + eps), norms = |y|.
 __global__ void __launch_bounds__(256) l2norm_fwd_kernel(int64_t P, int N, const float *__restrict__ y, float eps,
                                                          float *__restrict__ out, float *__restrict__ norms) {
@@ -314,6 +438,14 @@ int launch_fwd(int64_t P, int M, const float *X, int ldx, int Kx, const u4v *pac
 }
 
 }  // namespace
+
+static int tuning_wgrad_wide() {
+  static const int v = [] {
+    const char *e = getenv("POGS_DENSE_WGRAD_WIDE");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
 }  // namespace pr
 
 extern "C" size_t pr_dense_packed_bytes(int M, int K) {
@@ -363,8 +495,15 @@ extern "C" int pr_dense_wgrad(int64_t P, int N, int K, const float *G, int ldg, 
   if (P < 0 || N <= 0 || K <= 0) return PR_EINVAL;
   if (P == 0) return PR_OK;
   if (!G || !H || !dW || ldg < N || ldh < K || ldw < K) return PR_EINVAL;
-  const unsigned gx = (unsigned)((N + pr::WG_N - 1) / pr::WG_N), gy = (unsigned)((K + pr::WG_K - 1) / pr::WG_K);
   const int64_t steps = (P + 31) / 32;
+  // POGS_DENSE_WGRAD_WIDE=0: the 128 x 64 tiles everywhere (A/B runs).  (128-row blocks, two workgroups per CU, need
+  // 48 registers of prefetch next to 128 of accumulators: they spill, 23.8 ms against 12 for the heads' backward.)
+  if (pr::tuning_wgrad_wide() && N % 256 == 0 && K <= 256) {
+    hipStream_t st = (hipStream_t)stream;
+    return K <= 128 ? pr::launch_wgrad_wide<256, 4>(P, N, K, G, ldg, H, ldh, dW, ldw, st)
+                    : pr::launch_wgrad_wide<256, 8>(P, N, K, G, ldg, H, ldh, dW, ldw, st);
+  }
+  const unsigned gx = (unsigned)((N + pr::WG_N - 1) / pr::WG_N), gy = (unsigned)((K + pr::WG_K - 1) / pr::WG_K);
   int64_t gz = std::max<int64_t>(1, 2048 / ((int64_t)gx * gy));  // about eight workgroups per CU in flight
   gz = std::min(gz, std::max<int64_t>(1, steps / 4));           // at least four steps per workgroup
   hipLaunchKernelGGL(pr::dense_wgrad_kernel, dim3(gx, gy, (unsigned)gz), dim3(256), 0, (hipStream_t)stream, P, N, K, G,
