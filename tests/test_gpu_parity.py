@@ -613,6 +613,31 @@ def test_binning_of_one_call_serves_another(gpu):
         rd.rasterization(means=means, colors=sc.features.to(gpu), binning=meta["binning"], **{**a, "tile_size": 8})
 
 
+def test_large_model_with_nothing_in_view(gpu):
+    """A model large enough for the depth sort on the second stream, every Gaussian behind the camera: no intersection,
+    background-only images, zero gradients -- also through depth_order= and binning= of that empty render."""
+    rd = _rendering()
+    from pogs_amd.scenes import make_scene
+
+    sc = make_scene(120_000, 160, 96, n_features=8, seed=6)
+    means = sc.means.clone()
+    means[:, 2] -= 50.0                     # the camera looks down +z from z = -3
+    means = means.to(gpu).requires_grad_(True)
+    feats = sc.features.to(gpu).requires_grad_(True)
+    a = dict(quats=sc.quats.to(gpu), scales=sc.log_scales.exp().to(gpu), opacities=torch.sigmoid(sc.opacity_logits).to(gpu),
+             viewmats=sc.viewmats[:1].to(gpu), Ks=sc.Ks[:1].to(gpu), width=160, height=96, packed=False)
+    bg = torch.full((1, 8), 0.25, device=gpu)
+    out, alpha, meta = rd.rasterization(means=means, colors=feats, backgrounds=bg, **a)
+    assert meta["n_composited_isects"] == 0 and int((meta["radii"] > 0).sum()) == 0
+    assert torch.equal(alpha, torch.zeros_like(alpha)) and torch.equal(out, torch.full_like(out, 0.25))
+    (out.sum() + alpha.sum()).backward()
+    assert float(means.grad.abs().max()) == 0.0 and float(feats.grad.abs().max()) == 0.0
+    with torch.no_grad():
+        for kw in (dict(depth_order=meta["depth_order"]), dict(binning=meta["binning"])):
+            o2, a2, m2 = rd.rasterization(means=means, colors=feats, backgrounds=bg, **kw, **a)
+            assert m2["n_composited_isects"] == 0 and torch.equal(o2, out.detach()) and torch.equal(a2, alpha.detach())
+
+
 def test_forward_planner_on_small_and_large_images(gpu, tuning):
     """Many tiles: the vector kernel at two pixels per lane, passes of up to 48 channels.  Few tiles and 16 channels or
     more: the per-block walks (two pixels per lane as well), passes of up to 32 channels; the vector kernel with narrow
