@@ -258,6 +258,19 @@ int pr_track_loss_bwd(int64_t P, int D, const float *rendered, const float *targ
                       const float *target_depth, const uint8_t *valid, float inv_scale, float cut2, float mult,
                       const float *sums, const float *v_loss, float *v_rendered, float *v_depth, void *stream);
 
+/* Depth masks of the tracker's per-object crops (pogs/tracking/rigid_group_optimizer.py:316-337), all crops of a pass at
+ * once: crop g occupies the top-left sizes[g] = (h, w) window of image g of a padded [G, Hm, Wm] batch.
+ *   valid = accumulation > acc_min (0.85) and observed_depth is not NaN; eroded 5x5;
+ *   pixels whose observed depth exceeds reject_factor (1.3) x the crop's median over that mask are dropped
+ *   (torch.median: the lower middle value; a crop without a valid pixel drops nothing);
+ *   keep = 9x9 erosion of (mask and observed_depth != 0); masked_depth = keep ? observed_depth : 0.
+ * Erosions ignore what lies beyond a crop.  scratch: pr_roi_depth_masks_scratch_bytes(G, Hm, Wm) bytes, 16-byte aligned;
+ * medians[G] receives the medians (NaN: none). */
+size_t pr_roi_depth_masks_scratch_bytes(int G, int Hm, int Wm);
+int pr_roi_depth_masks(int G, int Hm, int Wm, const int32_t *sizes, const float *accumulation,
+                       const float *observed_depth, float acc_min, float reject_factor, uint8_t *scratch,
+                       float *medians, uint8_t *keep, float *masked_depth, void *stream);
+
 /* ---- rigid-group transform of the Gaussian model (the tracker's per-iteration pose update) ----
  * Replaces the Warp kernel apply_to_model (pogs/tracking/utils.py:53-93, launched at
  * pogs/tracking/rigid_group_optimizer.py:466-477) and its wp.Tape backward (:413-430).

@@ -79,6 +79,8 @@ SIGNATURES = {
     "pr_track_loss_bwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P, _P]),
     "pr_rigid_fwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pr_rigid_bwd": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pr_roi_depth_masks_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pr_roi_depth_masks": (c_int, [c_int, c_int, c_int, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P]),
     "pr_pose_step": (c_int, [c_int, _P, _P, _P, _P, c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                              ctypes.c_double, c_int, _P]),
 }

@@ -143,6 +143,52 @@ def identity_7vec(device="cuda") -> Tensor:
     return torch.tensor([[0, 0, 0, 1, 0, 0, 0]], dtype=torch.float32, device=device)
 
 
+@torch.no_grad()
+def roi_depth_masks(acc: Tensor, observed_depth: Tensor, sizes: Tensor, own: Optional[Tensor] = None,
+                    acc_min: float = 0.85, reject_factor: float = 1.3):
+    """Depth masks of the per-object crops (``rigid_group_optimizer.py:316-337``) for all crops of a pass in four
+    launches (``pr_roi_depth_masks``).  ``acc`` (rendered accumulation) and ``observed_depth`` (NaN where unobserved):
+    [G,Hm,Wm]; crop g is the top-left ``sizes[g] = (h, w)`` window of image g.  -> (keep [G,Hm,Wm] bool, the observed
+    depth where kept, else 0).  ``own`` is not needed (the windows come from ``sizes``)."""
+    if not acc.is_cuda:
+        raise RuntimeError("pogs_amd.tracking needs tensors on a HIP device: there is no CPU fallback")
+    G, Hm, Wm = acc.shape
+    acc, observed_depth = acc.contiguous().float(), observed_depth.contiguous().float()
+    assert observed_depth.shape == acc.shape and sizes.shape == (G, 2) and sizes.dtype == torch.int32
+    dev = acc.device
+    scratch = torch.empty(_lib.load().pr_roi_depth_masks_scratch_bytes(G, Hm, Wm), dtype=torch.uint8, device=dev)
+    medians = torch.empty(G, dtype=torch.float32, device=dev)
+    keep = torch.empty(G, Hm, Wm, dtype=torch.uint8, device=dev)
+    masked = torch.empty(G, Hm, Wm, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _call("pr_roi_depth_masks", G, Hm, Wm, _ptr(sizes.contiguous()), _ptr(acc), _ptr(observed_depth), float(acc_min),
+              float(reject_factor), _ptr(scratch), _ptr(medians), _ptr(keep), _ptr(masked), _stream())
+    return keep.view(torch.bool), masked
+
+
+@torch.no_grad()
+def roi_depth_masks_torch(acc: Tensor, observed_depth: Tensor, sizes: Tensor, own: Tensor, acc_min: float = 0.85,
+                          reject_factor: float = 1.3):
+    """The same masks from PyTorch operators (about forty launches and a sort-based median): what the fused kernels
+    are tested against.  ``own`` [G,Hm,Wm] bool: each crop's own pixels."""
+    G = own.shape[0]
+    t_depth = observed_depth
+    valid = (acc > acc_min) & ~t_depth.isnan()
+
+    # erosions see the pixels beyond a crop as set, as the crop's own border is seen when it is processed alone
+    def erode(m, k):
+        x = (m | ~own)[:, None].float()
+        return (-torch.nn.functional.max_pool2d(-x, k, stride=1, padding=k // 2))[:, 0] > 0.5
+
+    valid_depths = erode(valid, 5) & own
+    med = torch.where(valid_depths, t_depth, torch.full_like(t_depth, float("nan"))).view(G, -1).nanmedian(dim=1).values
+    reject = t_depth > (med * reject_factor)[:, None, None]     # (a crop without a valid depth: nan, rejects nothing)
+    valid_depths = valid_depths & ~reject
+    masked = torch.where(valid_depths, t_depth, torch.zeros_like(t_depth))
+    keep = erode(valid_depths & (masked != 0), 9) & own
+    return keep, torch.where(keep, masked, torch.zeros_like(masked))
+
+
 class TrackingLoop:
     """The tracker's per-frame pose optimisation around the rasterizer, as ``RigidGroupOptimizer.step`` runs it
     (``pogs/tracking/rigid_group_optimizer.py:402-453`` with ``get_optim_loss`` ``:278-400`` on the whole-frame
@@ -199,6 +245,8 @@ class TrackingLoop:
         # (rasterization(binning=...)); False: tile 8 then tile 16 as the reference, sharing the depth order only
         self.share_binning = True
         self.skip_unused_rgb = False
+        # per-object branch: the crops' depth masks from pr_roi_depth_masks (False: from PyTorch operators)
+        self.fused_roi_masks = True
         self.shared_tile = 16       # (8 for both measured the same: 57.5 against 56.7 ms per frame)
         # True: RGB+ED and the features as ONE render of 68 channels (whole-frame branch)
         self.fuse_renders = False
@@ -415,20 +463,16 @@ class TrackingLoop:
         dino, depth, acc = self.render_rois(self.part_deltas)
         if not (use_depth and t_depth is not None):
             return tracking_loss(dino, t_dino)
-        G = own.shape[0]
-        valid = (acc[..., 0] > 0.85) & ~t_depth.isnan()
-        # erosions see the pixels beyond a crop as set, as the crop's own border is seen when it is processed alone
-        def erode(m, k):
-            x = (m | ~own)[:, None].float()
-            return (-torch.nn.functional.max_pool2d(-x, k, stride=1, padding=k // 2))[:, 0] > 0.5
-        valid_depths = erode(valid, 5) & own
-        med = torch.where(valid_depths, t_depth, torch.full_like(t_depth, float("nan"))).view(G, -1).nanmedian(dim=1).values
-        reject = t_depth > (med * 1.3)[:, None, None]          # (a crop without a valid depth: nan, rejects nothing)
-        valid_depths = valid_depths & ~reject
-        masked = torch.where(valid_depths, t_depth, torch.zeros_like(t_depth))
-        keep = erode(valid_depths & (masked != 0), 9) & own
-        return tracking_loss(dino, t_dino, depth[..., 0], torch.where(keep, masked, torch.zeros_like(masked)), keep,
-                             self.dataset_scale, self.depth_ignore_threshold, self.depth_loss_mult)
+        keep, masked = (roi_depth_masks if self.fused_roi_masks else roi_depth_masks_torch)(
+            acc[..., 0].detach(), t_depth, self._roi_sizes(), own)
+        return tracking_loss(dino, t_dino, depth[..., 0], masked, keep, self.dataset_scale, self.depth_ignore_threshold,
+                             self.depth_loss_mult)
+
+    def _roi_sizes(self) -> Tensor:
+        if getattr(self, "_roi_size_table", None) is None:
+            self._roi_size_table = torch.tensor([[r["height"], r["width"]] for r in self.rois], dtype=torch.int32,
+                                                device=self.means.device)
+        return self._roi_size_table
 
     def _roi_loss(self, use_depth: bool) -> Tensor:
         if self.batch_rois:

@@ -229,6 +229,12 @@ def test_rigid_entry_points_validate_arguments_without_a_gpu():
     assert lib.pr_pose_step(0, None, None, None, None, 1, 0.004, 0.9, 0.999, 1e-8, 1, None) == 0
     assert lib.pr_pose_step(4, None, None, None, None, 1, 0.004, 0.9, 0.999, 1e-8, 1, None) == -1   # null pointers
     assert lib.pr_pose_step(4, None, None, None, None, 0, 0.004, 0.9, 0.999, 1e-8, 1, None) == -1   # step counts from 1
+    assert lib.pr_roi_depth_masks(-1, 4, 4, None, None, None, 0.85, 1.3, None, None, None, None, None) == -1
+    assert lib.pr_roi_depth_masks(0, 4, 4, None, None, None, 0.85, 1.3, None, None, None, None, None) == 0
+    assert lib.pr_roi_depth_masks(2, 4, 4, None, None, None, 0.85, 1.3, None, None, None, None, None) == -1
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        from pogs_amd.tracking import roi_depth_masks
+        roi_depth_masks(torch.zeros(1, 4, 4), torch.zeros(1, 4, 4), torch.tensor([[4, 4]], dtype=torch.int32))
     assert lib.pr_rigid_fwd(-1, 1, None, None, None, None, None, None, None, None) == -1
     assert lib.pr_rigid_fwd(0, 0, None, None, None, None, None, None, None, None) == 0   # nothing to do
     assert lib.pr_rigid_fwd(4, 1, None, None, None, None, None, None, None, None) == -1  # null pointers

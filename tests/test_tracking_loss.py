@@ -69,3 +69,41 @@ def test_tracking_loss_without_a_finite_pixel_is_nan(gpu):
     r = torch.zeros(4, 64, device=gpu)
     t = torch.full((4, 64), float("nan"), device=gpu)
     assert float(tracking_loss(r, t)) != float(tracking_loss(r, t))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_crop_depth_masks_match_the_operator_sequence(gpu, seed):
+    """pr_roi_depth_masks against the same masks from PyTorch operators (rigid_group_optimizer.py:316-337: threshold,
+    5x5 erosion, rejection above 1.3 x the median, non-zero, 9x9 erosion): crops of different sizes in one padded batch,
+    unobserved (NaN) and zero depths, far outliers, a crop without any valid pixel."""
+    from pogs_amd.tracking import roi_depth_masks, roi_depth_masks_torch
+
+    gen = torch.Generator().manual_seed(seed)
+    sizes = [(70, 98), (56, 42), (84, 112), (28, 14)]
+    G, Hm, Wm = len(sizes), 84, 112
+    acc = torch.zeros(G, Hm, Wm)
+    obs = torch.full((G, Hm, Wm), float("nan"))
+    own = torch.zeros(G, Hm, Wm, dtype=torch.bool)
+    yy, xx = torch.meshgrid(torch.arange(Hm), torch.arange(Wm), indexing="ij")
+    for g, (h, w) in enumerate(sizes):
+        own[g, :h, :w] = True
+        # a covered blob in the middle with a ragged edge, depth around 0.5 with outliers, holes and zeros
+        blob = ((yy - h / 2) / (0.45 * h)) ** 2 + ((xx - w / 2) / (0.45 * w)) ** 2 < 1.0 + 0.2 * torch.rand(Hm, Wm, generator=gen)
+        acc[g] = torch.where(blob, 0.86 + 0.14 * torch.rand(Hm, Wm, generator=gen), 0.8 * torch.rand(Hm, Wm, generator=gen))
+        d = 0.5 + 0.05 * torch.randn(Hm, Wm, generator=gen)
+        r = torch.rand(Hm, Wm, generator=gen)
+        d = torch.where(r < 0.002, d * 2.0, d)                              # far behind the object
+        d = torch.where((r >= 0.002) & (r < 0.004), torch.zeros_like(d), d)   # zeros
+        d = torch.where((r >= 0.004) & (r < 0.006), torch.full_like(d, float("nan")), d)
+        obs[g, :h, :w] = d[:h, :w]
+    acc[3] = 0.1                                                            # crop 3: nothing covered
+    acc, obs, own = acc.to(gpu), obs.to(gpu), own.to(gpu)
+    table = torch.tensor(sizes, dtype=torch.int32, device=gpu)
+    keep, masked = roi_depth_masks(acc, obs, table)
+    keep_ref, masked_ref = roi_depth_masks_torch(acc, obs, table, own)
+    assert keep.dtype == torch.bool and torch.equal(keep, keep_ref)
+    assert torch.equal(masked, masked_ref)
+    assert int(keep[0].sum()) > 300 and int(keep[3].sum()) == 0 and not bool(keep[~own].any())
+    # the rejection did something, and so did the second erosion
+    assert int(keep.sum()) < int(((acc > 0.85) & ~obs.isnan() & own).sum()) - 200
