@@ -18,6 +18,8 @@
 //    (rows of a matrix product are independent, so rows not yet filled may hold anything).
 //  * What stays on the vector unit per iteration: alpha, the transmittance recurrence, the geometry terms and
 //    their two lane-swap folds.
+#include <algorithm>
+
 #include "raster_common.h"
 
 namespace pr {
@@ -506,6 +508,32 @@ int launch_bwd_mm(int cd, int tile_size, bool geom_grad, bool color_grad, bool s
   // window, 96 channels at 960x540 after the geometry launch 1.01 -> 0.94.  Narrower windows do not pay, on small images
   // either (every window repeats the walk): 0.22 ms with four windows of 16 in the first case.
   const int widest = tuning().bwd_window > 0 ? tuning().bwd_window : 48;
+  // Few channels want gradients (a wide image of frozen features with a depth or colour channel at either end): only
+  // the 16-channel blocks that hold a wanted channel are walked, one launch per run of such blocks.
+  {
+    int lo[3], hi[3], n_runs = 0, wanted = 0;
+    for (int i = 0; i < gs.n; ++i) {
+      if (!gs.ptr[i]) continue;
+      const int b = gs.begin[i], e = i + 1 < gs.n ? gs.begin[i + 1] : D;
+      const int a0 = b & ~15, a1 = std::min(D, (e + 15) & ~15);
+      if (n_runs && a0 <= hi[n_runs - 1]) hi[n_runs - 1] = std::max(hi[n_runs - 1], a1);   // (segments are in channel order)
+      else lo[n_runs] = a0, hi[n_runs] = a1, ++n_runs;
+    }
+    for (int r = 0; r < n_runs; ++r) wanted += hi[r] - lo[r];
+    if (n_runs > 0 && 2 * wanted <= D) {
+      n_pass = 1;
+      for (int r = 0; r < n_runs; ++r)
+        for (int off = lo[r]; off < hi[r]; off += 48) {
+          per = std::min(48, (hi[r] - off + 15) & ~15);
+          rc = PR_EUNSUPPORTED;
+          switch (per <= 16 ? 16 : per <= 32 ? 32 : 48) {
+            MM_CASE(16, MM_COLOUR, off) MM_CASE(32, MM_COLOUR, off) MM_CASE(48, MM_COLOUR, off)
+          }
+          if (rc) return rc;
+        }
+      return rc;
+    }
+  }
   const int n_win = (D + widest - 1) / widest;
   per = ((D + n_win - 1) / n_win + 15) & ~15;
   n_pass = (D + per - 1) / per;

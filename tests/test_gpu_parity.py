@@ -638,6 +638,33 @@ def test_large_model_with_nothing_in_view(gpu):
             assert m2["n_composited_isects"] == 0 and torch.equal(o2, out.detach()) and torch.equal(a2, alpha.detach())
 
 
+@pytest.mark.parametrize("tile_size", [16, 8])
+def test_backward_with_frozen_wide_features(gpu, tile_size):
+    """RGB + expected depth around 64 FROZEN feature channels: only the channel blocks that hold a wanted channel (rgb at
+    the front, depth at the end) are walked for colour gradients.  Same gradients as the call in which the features
+    want theirs too (every window walked)."""
+    rd = _rendering()
+    from pogs_amd.scenes import make_scene
+
+    sc = make_scene(20_000, 200, 120, n_features=64, seed=8)
+    cot = torch.randn(1, 120, 200, 68, device=gpu)
+    cot_a = torch.randn(1, 120, 200, 1, device=gpu)
+    got = []
+    for frozen in (False, True):
+        leaves = {k: v.to(gpu).requires_grad_(True) for k, v in dict(means=sc.means, quats=sc.quats, ls=sc.log_scales,
+                                                                       ol=sc.opacity_logits, sh=sc.sh).items()}
+        feats = sc.features.to(gpu).requires_grad_(not frozen)
+        out, alpha, _ = rd.rasterization(leaves["means"], leaves["quats"], leaves["ls"].exp(), torch.sigmoid(leaves["ol"]),
+                                         leaves["sh"], sc.viewmats[:1].to(gpu), sc.Ks[:1].to(gpu), 200, 120, sh_degree=3,
+                                         render_mode="RGB+ED", packed=False, tile_size=tile_size, features=feats)
+        torch.autograd.backward([out, alpha], [cot, cot_a])
+        got.append({k: v.grad for k, v in leaves.items()})
+        assert (feats.grad is None) == frozen
+    for k in got[0]:
+        scale = float(got[0][k].abs().max())
+        assert scale > 0 and float((got[0][k] - got[1][k]).abs().max()) <= 2e-4 * scale, k
+
+
 def test_forward_planner_on_small_and_large_images(gpu, tuning):
     """Many tiles: the vector kernel at two pixels per lane, passes of up to 48 channels.  Few tiles and 16 channels or
     more: the per-block walks (two pixels per lane as well), passes of up to 32 channels; the vector kernel with narrow
